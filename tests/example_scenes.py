@@ -1,0 +1,154 @@
+"""The reference's example scene scripts re-expressed in the test DSL (test infrastructure).
+
+Scene constants are taken from the reference's scene scripts (data, not code):
+  examples/single-triangle.rs:17-58, examples/primitives-simple.rs:17-76,
+  examples/macho-cows.rs:17-128, examples/entering-the-mirror-dimension.rs:17-188,
+  examples/big-scene.rs:26-109.
+The product has its own C++ transliteration of the same scripts (examples/*.cpp); the tests check
+that both produce identical node matrices.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from rand07 import StdRng
+from scene_dsl import (ASSETS, Camera, Cone, Cube, Cylinder, Light, Material, Mesh, MeshData, Node, Plane, Scene, Sphere,
+                       Triangle, to_radians)
+
+_mesh_cache = {}
+
+
+def load_mesh(name: str) -> MeshData:
+    if name not in _mesh_cache:
+        _mesh_cache[name] = MeshData.load_obj(os.path.join(ASSETS, name))
+    return _mesh_cache[name]
+
+
+def single_triangle():
+    mat1 = Material(diffuse=(0.541, 0.169, 0.886), specular=(0.5, 0.7, 0.5), shininess=25.0)
+    tri = Triangle((-1.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.5, 0.0))
+    scene = Scene(root=Node.group([Node.geo(tri, mat1)]),
+                  lights=[Light(position=(1.0, 1.0, 10.0), color=(0.5, 0.5, 0.5))],
+                  ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.0, 0.5, 4.0), center=(0.0, 0.5, 0.0), fovy_degrees=50.0)
+    return scene, cam, (640, 480)
+
+
+def primitives_simple():
+    mat_grass = Material(diffuse=(0.173224, 0.8, 0.226505))
+    mat_cylinder = Material(diffuse=(0.139339, 0.435762, 0.8), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    mat_cone = Material(diffuse=(0.8, 0.047361, 0.04305), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    scene = Scene(
+        root=Node.group([
+            Node.geo(Cylinder(), mat_cylinder).scaled(2.0).translated((-2.0, 1.0, 0.0)),
+            Node.geo(Cone(), mat_cone).scaled(2.0).translated((2.0, 1.0, 0.0)),
+            Node.geo(Plane(), mat_grass).scaled(10.0),
+        ]),
+        lights=[Light(position=(0.0, 10.0, 9.0), color=(0.9, 0.9, 0.9))],
+        ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.760838, 8.095396, 10.50759), center=(-0.41716, -3.477774, -5.761218), fovy_degrees=25.0)
+    return scene, cam, (910, 512)
+
+
+def macho_cows():
+    stone = Material(diffuse=(0.8, 0.7, 0.7))
+    grass = Material(diffuse=(0.1, 0.7, 0.1))
+    cow_hide = Material(diffuse=(0.84, 0.6, 0.53), specular=(0.3, 0.3, 0.3), shininess=20.0)
+    cow_model, plane, buckyball = load_mesh("cow.obj"), load_mesh("plane.obj"), load_mesh("buckyball.obj")
+    arc = Node.group([
+        Node.geo(Cube(), stone).scaled((0.8, 4.0, 0.8)).translated((-2.0, 2.0, 0.0)),
+        Node.geo(Cube(), stone).scaled((0.8, 4.0, 0.8)).translated((2.0, 2.0, 0.0)),
+        Node.geo(Sphere(), stone).scaled((4.0, 0.6, 0.6)).translated((0.0, 4.0, 0.0)),
+    ]).translated((0.0, 0.0, -10.0))
+    nodes = [Node.group([arc]).rotated_y(to_radians(60.0 * float(i - 1))) for i in range(1, 7)]
+    cow = Node.geo(Mesh(cow_model), cow_hide).translated((0.0, 3.637, 0.0)).scaled(2.0 / (2.76 + 3.637)).translated((0.0, -1.0, 0.0))
+    cows = [((1.0, 1.3, 14.0), 20.0), ((5.0, 1.3, -11.0), 180.0), ((-5.5, 1.3, -3.0), -60.0)]
+    for pos, rot in cows:
+        nodes.append(Node.group([cow]).scaled(1.4).rotated_y(to_radians(rot)).translated(pos))
+    nodes.append(Node.geo(Mesh(plane), grass).scaled(30.0))
+    nodes.append(Node.geo(Mesh(buckyball), stone).scaled(1.5))
+    scene = Scene(root=Node.group(nodes).rotated_x(to_radians(23.0)),
+                  lights=[Light(position=(200.0, 202.0, 430.0), color=(0.8, 0.8, 0.8))],
+                  ambient=(0.4, 0.4, 0.4))
+    cam = Camera(eye=(0.0, 2.0, 30.0), center=(0.0, 2.0, 29.0), fovy_degrees=50.0)
+    return scene, cam, (256, 256)
+
+
+def mirror_dimension():
+    mat_mirror_frame = Material(diffuse=(0.29, 0.204, 0.145), shininess=1.0)
+    mat_mirror = Material(diffuse=(0.0, 0.0, 0.0), specular=(0.8, 0.8, 0.8), shininess=1000.0, reflectivity=1.0)
+    mat_floor = Material(diffuse=(0.016, 0.384, 0.0), specular=(0.8, 0.8, 0.8), shininess=25.0)
+    mat_body = Material(diffuse=(0.906, 0.22, 0.282), specular=(0.8, 0.8, 0.8), shininess=25.0)
+    mat_head = Material(diffuse=(0.086, 0.671, 0.906), specular=(0.8, 0.8, 0.8), shininess=50.0)
+    mat_eyes = Material(diffuse=(0.3, 0.3, 0.3), specular=(0.8, 0.8, 0.8), shininess=1000.0, reflectivity=0.9)
+    mat_arms = Material(diffuse=(0.345, 0.588, 0.906), specular=(0.8, 0.8, 0.8), shininess=1.0)
+    monkey, plane = load_mesh("monkey.obj"), load_mesh("plane.obj")
+    deg = lambda v: tuple(to_radians(a) for a in v)
+    mirror = Node.group([
+        Node.geo(Cube(), mat_mirror_frame).scaled((3.96, 5.5, 0.4)).translated((0.0, 2.75, 0.0)),
+        Node.geo(Cube(), mat_mirror).scaled((3.6, 5.0, 0.1)).translated((0.0, 2.75, 0.2)),
+    ]).translated((0.0, 0.0, -1.3))
+    monkey_character = Node.group([
+        Node.geo(Cube(), mat_body).scaled((0.545055, 2.6, 0.545055)).translated((0.0, 1.3, 0.0)),
+        Node.geo(Mesh(monkey), mat_head).scaled((1.0, 1.0, 1.0)).rotated_y(to_radians(180.0)).translated((0.0, 2.7, 0.0))
+            .with_children([
+                Node.geo(Sphere(), mat_eyes).scaled((0.1, 0.1, 0.05)).translated((0.35, 0.24, 0.8)),
+                Node.geo(Sphere(), mat_eyes).scaled((0.1, 0.1, 0.05)).translated((-0.35, 0.24, 0.8)),
+            ]),
+        Node.geo(Sphere(), mat_arms).scaled((0.2, 0.63, 0.2)).rotated_xzy(deg((161.156, 107.062, -133.944))).translated((-0.388703, 1.715599, -0.2)),
+        Node.geo(Sphere(), mat_arms).scaled((0.2, 0.56, 0.2)).rotated_xzy(deg((127.221, 42.0695, -104.823))).translated((-0.711297, 1.284401, -1.0)),
+        Node.geo(Sphere(), mat_mirror).scaled((0.5, 0.5, 0.3)).translated((-0.711297, 1.284401, -1.20)),
+        Node.geo(Sphere(), mat_arms).scaled((0.2, 0.63, 0.2)).rotated_xzy(deg((92.3684, -57.6199, 38.2278))).translated((0.581161, 1.984976, -0.2)),
+        Node.geo(Sphere(), mat_arms).scaled((0.2, 0.56, 0.2)).rotated_xzy(deg((91.5166, -11.239, 28.419))).translated((1.118839, 2.015024, -1.0)),
+        Node.geo(Sphere(), mat_mirror).scaled((0.5, 0.5, 0.3)).translated((1.118839, 2.015024, -1.20)),
+    ])
+    floor = Node.geo(Mesh(plane), mat_floor).scaled(20.0)
+    scene = Scene(root=Node.group([mirror, floor, monkey_character]),
+                  lights=[Light(position=(2.5, 3.5, -1.0), color=(0.9, 0.9, 0.9)),
+                          Light(position=(10.0, 10.0, 0.0), color=(0.9, 0.9, 0.9)),
+                          Light(position=(-9.0, 4.0, 0.0), color=(0.406471, 0.901283, 1.0))],
+                  ambient=(0.2, 0.2, 0.2))
+    cam = Camera(eye=(5.545485, 2.966984, 1.795613), center=(-4.348584, 2.148794, -3.057839), fovy_degrees=30.0)
+    return scene, cam, (800, 600)
+
+
+def big_scene(n: int = 10, prims=None):
+    """examples/big-scene.rs:26-109; `prims` replaces the primitive list (synthetic variants)."""
+    rng = StdRng.seed_from_u64(1234939301)
+    materials = []
+    for _ in range(15):
+        r = rng.gen_f64(); g = rng.gen_f64(); b = rng.gen_f64()
+        materials.append(Material(diffuse=(r, g, b), specular=(0.3, 0.3, 0.3), shininess=25.0))
+    primitives = prims if prims is not None else [Sphere, Cube, Cone, Cylinder]
+    width = length = height = 800.0
+    nodes = []
+    for i in range(n):
+        x = float(i) / float(n - 1) * width - width / 2.0
+        for j in range(n):
+            y = float(j) / float(n - 1) * length - length / 2.0
+            for k in range(n):
+                z = float(k) / float(n - 1) * height - height / 2.0
+                prim = rng.choose(primitives)
+                mat = rng.choose(materials)
+                scale = 30.0 * rng.gen_f64() + 30.0
+                angle = to_radians(360.0 * rng.gen_f64())
+                yy = y + rng.gen_f64() * 50.0
+                nodes.append(Node.geo(prim(), mat).scaled(scale).rotated_xzy((angle, angle, angle)).translated((x, yy, z)))
+    scene = Scene(root=Node.group(nodes),
+                  lights=[Light(position=(-100.0, 150.0, 400.0), color=(0.9, 0.9, 0.9)),
+                          Light(position=(100.0, -150.0, 800.0), color=(0.7, 0.7, 0.7)),
+                          Light(position=(400.0, 100.0, 150.0), color=(0.7, 0.0, 0.7))],
+                  ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.0, 0.0, 1200.0), center=(0.0, 0.0, 0.0), fovy_degrees=50.0)
+    return scene, cam, (1980, 1020)
+
+
+EXAMPLES = {
+    "single-triangle": single_triangle,
+    "primitives-simple": primitives_simple,
+    "macho-cows": macho_cows,
+    "entering-the-mirror-dimension": mirror_dimension,
+    "big-scene": big_scene,
+}

@@ -1,0 +1,127 @@
+"""Pins the oracle against the reference's committed renders.
+
+The goldens were rendered with random anti-aliasing (thread_rng, unknown SAMPLES), so a
+centre-sample oracle render must agree everywhere except on thin silhouette / shadow / facet
+edges; interior pixels and background rows are exact known answers."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from example_scenes import EXAMPLES
+from rand07 import StdRng
+from scene_dsl import GOLDEN
+
+
+def golden(name):
+    return np.array(Image.open(os.path.join(GOLDEN, "render", name)).convert("RGB"))
+
+
+def erode_mismatch(mask, px=2):
+    """True where a (2*px+1)^2 block of mismatching pixels survives: thin edges vanish."""
+    m = mask.copy()
+    for _ in range(px):
+        n = m.copy()
+        n[1:, :] &= m[:-1, :]; n[:-1, :] &= m[1:, :]; n[:, 1:] &= m[:, :-1]; n[:, :-1] &= m[:, 1:]
+        n[0, :] = n[-1, :] = False; n[:, 0] = n[:, -1] = False
+        m = n
+    return m
+
+
+@pytest.fixture(scope="module")
+def renders(oracle):
+    out = {}
+    for name, png, mode in [("primitives-simple", "01a_primitives-simple.png", oracle.MODE_HIER),
+                            ("entering-the-mirror-dimension", "entering-the-mirror-dimension.png", oracle.MODE_HIER),
+                            ("big-scene", "09a_kdtree.png", oracle.MODE_KD)]:
+        scene, cam, (w, h) = EXAMPLES[name]()
+        out[name] = (oracle.render(scene, cam, w, h, mode=mode), golden(png))
+    return out
+
+
+@pytest.mark.parametrize("name,exact_min,within1_min", [
+    ("primitives-simple", 0.989, 0.992),             # measured 99.01 % / 99.35 %
+    ("entering-the-mirror-dimension", 0.90, 0.96),   # measured 90.3 % / 96.6 % (noisy low-sample golden)
+    ("big-scene", 0.93, 0.96),                       # measured 93.3 % / 96.8 %
+])
+def test_centre_sample_matches_golden(renders, name, exact_min, within1_min):
+    r, g = renders[name]
+    assert r.rgb.shape == g.shape
+    d = np.abs(r.rgb.astype(int) - g.astype(int)).max(axis=2)
+    assert (d == 0).mean() >= exact_min
+    assert (d <= 1).mean() >= within1_min
+    assert not erode_mismatch(d > 8, 2).any(), "a mismatch blob thicker than an anti-aliased edge survived"
+    assert r.stats["kd_plane_miss"] == 0
+
+
+def test_background_rows_are_exact(renders):
+    for name, (r, g) in renders.items():
+        h = g.shape[0]
+        assert tuple(r.rgb[0, 0]) == (122, 168, 202) == tuple(g[0, 0]), name
+        assert tuple(r.rgb[h // 2, 0]) == (89, 122, 230) == tuple(g[h // 2, 0]), name
+
+
+def test_interior_known_answers(renders):  # SURVEY §8c-4 (x, y) -> rgb
+    ps = {(455, 450): (117, 235, 132), (100, 300): (112, 225, 126), (250, 260): (98, 165, 218),
+          (600, 330): (241, 66, 64), (700, 60): (115, 158, 209), (380, 230): (110, 222, 125)}
+    r, g = renders["primitives-simple"]
+    for (x, y), rgb in ps.items():
+        assert tuple(r.rgb[y, x]) == rgb == tuple(g[y, x]), (x, y)
+    md = {(560, 420): (70, 97, 240), (400, 50): (117, 161, 207), (680, 300): (164, 139, 119)}
+    r, g = renders["entering-the-mirror-dimension"]
+    for (x, y), rgb in md.items():
+        assert tuple(r.rgb[y, x]) == rgb == tuple(g[y, x]), (x, y)
+
+
+Q1_PIXELS = {(944, 653): (115, 75, 233), (1151, 731): (87, 177, 29), (1151, 719): (65, 133, 22), (1125, 734): (78, 159, 26),
+             (1160, 754): (54, 111, 18), (1159, 740): (86, 176, 29), (915, 642): (70, 46, 144), (1156, 735): (89, 180, 30)}
+
+
+def test_cone_quirk_q1_pixels_kd_exact(renders):  # results depend on the k-d tree (cone.rs:64-76)
+    r, g = renders["big-scene"]
+    for (x, y), rgb in Q1_PIXELS.items():
+        assert tuple(g[y, x]) == rgb, (x, y)
+        assert tuple(r.rgb[y, x]) == rgb, (x, y)
+
+
+def test_cone_quirk_q1_pixels_flat_differs(oracle):
+    """Flat semantics reproduces only the two '=' pixels of SURVEY §8c-5; the others differ."""
+    scene, cam, (w, h) = EXAMPLES["big-scene"]()
+    ps = oracle.pack(scene)
+    same = 0
+    for (x, y), rgb in Q1_PIXELS.items():
+        r = oracle.render(ps, cam, w, h, mode=oracle.MODE_FLAT, rect=(x, y, x, y), threads=1)
+        same += tuple(r.rgb[y, x]) == rgb
+    assert same == 2
+
+
+def test_rand07_known_answers():
+    r = StdRng.seed_from_u64(1234939301)
+    assert [f"{w:08x}" for w in r.key] == "bf1e3d47 eb93bac8 4f3b4401 4991de93 388161da 4c7039a4 d09a30e1 803dc311".split()
+    assert [f"{w:08x}" for w in r._block()[:4]] == "6df8b5e8 c53e7e25 9b646b73 4fa8aa27".split()
+    r = StdRng.seed_from_u64(1234939301)
+    assert [r.gen_f64() for _ in range(3)] == [0.770484813821869, 0.3111673685738353, 0.45554167289057856]
+
+
+def test_big_scene_first_node(oracle):  # first node = Cone, material 13, scale 37.84..., angle 352.12... deg
+    from scene_dsl import CONE
+    scene, _, _ = EXAMPLES["big-scene"]()
+    ps = oracle.pack(scene)
+    first = ps.lin.nodes[1]
+    assert first.geometry[0].kind == CONE
+    rng = StdRng.seed_from_u64(1234939301)
+    draws = [rng.gen_f64() for _ in range(45)]
+    assert tuple(first.geometry[1].diffuse) == tuple(draws[39:42])  # material 13
+    assert first.ops[0] == ("s", (37.8468300601445,) * 3)
+    assert abs(first.ops[1][1][0] * 180.0 / np.pi - 352.12624439923894) < 1e-12
+    assert first.ops[4][1][1] == -400.0 + 44.85171610632929
+
+
+def test_kd_tree_shape_big_scene(oracle):  # SURVEY App.C: depth 10 -> 1023 splits, 1024 leaves, 6806 refs, max leaf 12
+    scene, _, _ = EXAMPLES["big-scene"]()
+    tree = oracle.kd_scene_dump(scene, kd_depth=10)
+    kinds = tree["kind"]
+    assert (kinds == 0).sum() == 1023 and (kinds == 1).sum() == 1024
+    assert len(tree["items"]) == 6806
+    assert tree["count"][kinds == 1].max() == 12
