@@ -1,0 +1,191 @@
+/* portrayer_hip.h — C ABI of the MI355X (gfx950) ray-cast / shade path.
+ *
+ * This library replaces the body of the reference's pixel loop and everything it calls:
+ *   ImageSliceMut::render           src/render.rs:127-150   (the rayon loop over pixels)
+ *   render_single_pixel             src/render.rs:22-51
+ *   Camera::ray_at                  src/camera.rs:48-84
+ *   Ray::color, RayCast / RayHit    src/ray.rs:39-148
+ *   FlatSceneNode::ray_cast         src/flat_scene.rs:71-99
+ *   KDTreeNode::ray_cast_impl       src/kdtree/node.rs:66-203
+ *   Primitive::ray_hit dispatch     src/primitive.rs:55-62 and src/primitive/{sphere,triangle,mesh,cube,plane,cylinder,cone}.rs
+ *   BoundingBox::test_hit           src/bounding_box.rs:104-116
+ *   Material::hit_color             src/material.rs:91-320
+ * The reference has no FFI of its own (it is one Rust crate); these entry points are what a
+ * binding placed where render.rs:127-150 is today would call — INTEGRATION.md shows that binding.
+ * Host-side work that the reference does once per render stays with the caller and crosses this
+ * boundary as plain arrays: flattening (src/flat_scene.rs:18-46), matrix inverses, bounding boxes
+ * (src/bounding_box.rs:55-82, :123-148), the scene k-d tree build (src/kdtree/leaf.rs:89-231,
+ * src/kdtree/kdscene.rs:19-43), the camera matrix (src/camera.rs:34-45) and the background closure
+ * evaluated per integer pixel (src/render.rs:31-34).
+ *
+ * Conventions: every array is caller-owned, read-only for the duration of the call and may be
+ * freed afterwards; matrices are row-major 4x4 (16 doubles); no callbacks, no unwinding: every
+ * function returns 0 or a negative PT_ERR_* code and pt_last_error() describes the failure.
+ * One context per GPU; calls on one context must be serialised by the caller.
+ */
+#ifndef PORTRAYER_HIP_H
+#define PORTRAYER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+/* enum Primitive, src/primitive.rs:67-81 */
+enum { PT_PRIM_SPHERE = 0, PT_PRIM_TRIANGLE = 1, PT_PRIM_MESH = 2, PT_PRIM_KDMESH = 3, PT_PRIM_PLANE = 4, PT_PRIM_CUBE = 5, PT_PRIM_CYLINDER = 6, PT_PRIM_CONE = 7 };
+/* cargo features flat_scene / kdtree, src/render.rs:121-126 */
+enum { PT_TRAVERSE_FLAT = 1, PT_TRAVERSE_KD = 2 };
+/* sample position inside the pixel (the reference draws it from thread_rng, src/render.rs:38-39) */
+enum { PT_SAMPLE_CENTRE = 0, PT_SAMPLE_RNG = 1 };
+
+enum {
+    PT_OK = 0,
+    PT_ERR_ARGUMENT = -1,   /* null pointer, bad index, bad enum                                     */
+    PT_ERR_DEVICE = -2,     /* HIP runtime error (text in pt_last_error)                             */
+    PT_ERR_NO_SCENE = -3,   /* pt_render before pt_scene_upload                                      */
+    PT_ERR_SLICE = -4,      /* slice corner outside the image: ImageSliceMut::new panics, render.rs:79-90 */
+    PT_ERR_SCENE = -5,      /* inconsistent scene (mesh without vertices, mesh.rs:71; smooth shading without normals, mesh.rs:135-138) */
+    PT_ERR_TRAVERSAL = -6   /* a lane ran out of traversal stack (never expected; results invalid)    */
+};
+
+typedef struct pt_context pt_context;
+
+/* The flattened scene: Scene<Vec<FlatSceneNode>> (src/flat_scene.rs:16, :50-61), nodes in the
+ * breadth-first order FlatScene::from emits them (src/flat_scene.rs:18-46). */
+typedef struct {
+    uint32_t n_nodes;
+    const double *trans;          /* n_nodes x 16  FlatSceneNode::trans                                  */
+    const double *invtrans;       /* n_nodes x 16  trans.inverted()                (flat_scene.rs:104)    */
+    const double *normal_trans;   /* n_nodes x 16  invtrans.transposed()           (flat_scene.rs:105)    */
+    const int32_t *prim_type;     /* PT_PRIM_*                                                           */
+    const int32_t *prim_data;     /* MESH/KDMESH: mesh index; TRIANGLE: triangle index; else ignored     */
+    const int32_t *prim_flags;    /* bit 0: Shading::Smooth (mesh.rs:11-18) / triangle has vertex normals */
+    const int32_t *material;      /* index into materials                                                */
+    /* MeshData, src/primitive/mesh.rs:21-34 */
+    uint32_t n_meshes;
+    const uint64_t *mesh_vert_off;   /* n_meshes + 1, in vertices                                         */
+    const uint64_t *mesh_tri_off;    /* n_meshes + 1, in triangles                                        */
+    const double *mesh_positions;    /* total vertices x 3                                                */
+    const double *mesh_normals;      /* total vertices x 3, or NULL when no mesh has normals              */
+    const uint8_t *mesh_has_normals; /* n_meshes, or NULL                                                 */
+    const uint32_t *mesh_indices;    /* total triangles x 3, indices local to the mesh                    */
+    const double *mesh_bounds_invtrans; /* n_meshes x 16: BoundingBox::invtrans of the mesh AABB (bounding_box.rs:55-82) */
+    /* stand-alone Triangle primitives, src/primitive/triangle.rs:8-19 */
+    uint32_t n_triangles;
+    const double *tri_vertices;      /* n_triangles x 9: a, b, c                                          */
+    const double *tri_normals;       /* n_triangles x 9, or NULL                                          */
+    /* Material hot fields, src/material.rs:50-86: diffuse rgb, specular rgb, shininess, reflectivity,
+     * glossy_side_length, refraction_index */
+    uint32_t n_materials;
+    const double *materials;         /* n_materials x 10                                                  */
+    /* Light, src/light.rs:74-91: position, color, falloff c0 c1 c2, area.a, area.b */
+    uint32_t n_lights;
+    const double *lights;            /* n_lights x 15                                                     */
+    double ambient[3];               /* Scene::ambient, src/scene.rs:17                                   */
+} pt_scene;
+
+/* The scene k-d tree the host built (KDTreeScene::from, src/kdtree/kdscene.rs:19-43), linearised;
+ * node 0 is the root. Needed for PT_TRAVERSE_KD only. */
+typedef struct {
+    uint32_t n_nodes;
+    const int32_t *axis;      /* 0,1,2: KDTreeNode::Split on that axis; -1: KDTreeNode::Leaf (node.rs:13-25) */
+    const double *plane;      /* Split: sep_plane.point on `axis`                                         */
+    const int32_t *front;     /* Split: front_nodes                                                       */
+    const int32_t *back;      /* Split: back_nodes                                                        */
+    const int32_t *first;     /* Leaf: its nodes are leaf_items[first .. first + count), in Vec order      */
+    const int32_t *count;
+    uint32_t n_items;
+    const int32_t *leaf_items; /* flat node indices                                                       */
+    double root_min[3], root_max[3]; /* root bounds; extent() = squared diagonal (bounding_box.rs:95-99)   */
+    int32_t max_depth;        /* Split levels above the deepest leaf (sizes the traversal stack)          */
+} pt_kdtree;
+
+/* Camera, src/camera.rs:17-31, as Camera::new (camera.rs:34-45) computes it */
+typedef struct {
+    double eye[3];
+    double view_to_world[16];
+    double fov_factor;    /* tan(fovy / 2)  */
+    double aspect_ratio;  /* width / height */
+    double width, height;
+} pt_camera;
+
+typedef struct { uint32_t x0, y0, x1, y1; } pt_rect; /* inclusive corners like ImageSliceMut, render.rs:56-66 */
+
+typedef struct {
+    uint32_t width, height;     /* Image::width / height                                                 */
+    pt_rect slice;              /* pixels to render; others are left untouched (render.rs:135-138)        */
+    uint32_t samples;           /* env SAMPLES (render.rs:107-113), > 0                                   */
+    uint64_t seed;              /* key of the counter-based sample generator                             */
+    int32_t sample_mode;        /* PT_SAMPLE_*                                                            */
+    int32_t background_rows;    /* 1: background is height x 3 (one colour per row); 0: height x width x 3 */
+    uint32_t tile_rank;         /* multi-GPU: render only the 8x8 tiles t of the slice with              */
+    uint32_t tile_ranks;        /*   t % tile_ranks == tile_rank (1 GPU: 0 of 1)                          */
+    int32_t collect_stats;      /* 1: run the counting build of the kernel and fill ray/test counters     */
+} pt_render_params;
+
+typedef struct {
+    uint64_t primary, shadow, reflect, refract; /* rays traced                                           */
+    uint64_t depth11_skipped;   /* depth-11 rays the reference would trace and discard (material.rs:102-104) */
+    uint64_t hits;              /* shaded hits                                                           */
+    uint64_t n_inner, n_leaf;   /* tree nodes visited (bounding-volume nodes in FLAT, k-d nodes in KD)    */
+    uint64_t n_analytic;        /* flat-node candidate tests (ray transform + primitive dispatch)         */
+    uint64_t n_tri;             /* triangle tests                                                         */
+    uint64_t n_bbox;            /* mesh bounding-box tests                                                */
+    uint64_t kd_plane_miss;     /* places where the reference would panic (node.rs:146-147, :177-178)      */
+    uint64_t stack_overflow;    /* must be 0                                                              */
+    double kernel_ms;           /* device time of the render kernel (HIP events)                          */
+    double total_ms;            /* upload of per-call inputs + kernel + read-back                         */
+} pt_stats;
+
+int pt_abi_version(void);
+int pt_device_count(void);
+
+int pt_context_create(int device, pt_context **out);
+void pt_context_destroy(pt_context *ctx);
+const char *pt_last_error(const pt_context *ctx);
+
+/* Uploads the scene into HBM and builds the traversal structures. `traverse` = PT_TRAVERSE_*;
+ * `kd` must be non-NULL for PT_TRAVERSE_KD. Replaces any scene uploaded before. */
+int pt_scene_upload(pt_context *ctx, const pt_scene *scene, int traverse, const pt_kdtree *kd);
+
+/* Renders with host buffers. background: per pt_render_params.background_rows. rgb: height x width
+ * x 3 bytes, only pixels of the slice that belong to this tile rank are written. linear (optional):
+ * height x width x 3 doubles, the sample mean before gamma (render.rs:45). */
+int pt_render(pt_context *ctx, const pt_camera *camera, const double *background, const pt_render_params *params,
+              uint8_t *rgb, double *linear, pt_stats *stats);
+
+/* Same, writing into DEVICE memory on `hip_stream` (a hipStream_t, or NULL for the default stream)
+ * without synchronising the host: d_rgb is either the full image (compact = 0) or this rank's tiles
+ * only, tile-major, 8 x 8 x 3 bytes per tile (compact = 1; size = pt_compact_bytes()). The
+ * background must already be resident: d_background is a DEVICE pointer. stats (optional) are
+ * filled only if the call is followed by pt_render_finish(). */
+int pt_render_device(pt_context *ctx, const pt_camera *camera, const double *d_background, const pt_render_params *params,
+                     int compact, void *d_rgb, void *hip_stream);
+int pt_render_finish(pt_context *ctx, pt_stats *stats);
+
+/* Bytes of one rank's compact tile buffer for a slice split over tile_ranks ranks (equal for all ranks). */
+uint64_t pt_compact_bytes(const pt_render_params *params);
+/* Scatters the gathered compact buffers (rank-major) into a row-major image on the device. */
+int pt_untile_device(pt_context *ctx, const pt_render_params *params, const void *d_gathered, void *d_rgb, void *hip_stream);
+
+/* Device-side helpers used by the measurement harness. */
+int pt_device_alloc(pt_context *ctx, uint64_t bytes, void **out);
+int pt_device_free(pt_context *ctx, void *ptr);
+int pt_copy_to_device(pt_context *ctx, void *dst, const void *src, uint64_t bytes);
+int pt_copy_from_device(pt_context *ctx, void *dst, const void *src, uint64_t bytes);
+/* Streams `bytes` from src to dst with 16-byte accesses `iters` times and returns the best GB/s
+ * (read + write counted), the measured HBM roofline the renderer is compared with. */
+int pt_measure_copy_bandwidth(pt_context *ctx, uint64_t bytes, int iters, double *gbps);
+
+/* Self-test entry points for the parity tests: run device arithmetic on explicit inputs. */
+int pt_test_cast_rays(pt_context *ctx, uint64_t n, const double *origins, const double *directions, int any_hit,
+                      double *out_t, int32_t *out_node, int32_t *out_sub);
+int pt_test_math(pt_context *ctx, int op, uint64_t n, const double *a, const double *b, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

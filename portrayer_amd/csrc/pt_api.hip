@@ -1,0 +1,710 @@
+// gfx950 kernels and the C ABI declared in include/portrayer_hip.h.
+//
+// Kernel design (CDNA4: 64-wide wavefronts, 256 CUs in 8 XCDs, 160 KB LDS per CU, no matrix cores
+// involved — there is no dense contraction on this path):
+//  * persistent wavefronts: the grid is sized to what is resident on the chip; every lane owns one
+//    pixel at a time and loops over its samples in order (render.rs:36-43 summed in ascending
+//    order), then pulls the next pixel of the launch's 8x8-tile work list. Idle lanes are counted
+//    with __ballot / __popcll and ONE atomicAdd per wavefront hands out the next slots.
+//  * one traversal loop per wavefront for all ray kinds: pt_lane_advance() turns whatever the
+//    lane traced last (primary, shadow, reflected, refracted) into its next ray, so secondary rays
+//    re-enter the same loop instead of recursing (material.rs:242-243, :302-303).
+//  * traversal stack in LDS, one 32-bit column per lane (bank-conflict free by construction);
+//    recursion frames in HBM, SoA over lanes.
+//  * the scene stays resident in HBM / L2 after pt_scene_upload; a render moves only the camera
+//    (kernel argument), the background rows and the finished pixels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/portrayer_hip.h"
+#include "pt_bvh.h"
+#include "pt_shade.h"
+
+#define PT_BLOCK 256
+
+// ------------------------------------------------------------------------------------------------
+// Kernels
+// ------------------------------------------------------------------------------------------------
+template <int MODE, bool STATS>
+__device__ __forceinline__ void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const PtStack& stk, PtCounters* cnt) {
+    if (MODE == PT_MODE_KD) pt_trace_kd<STATS>(sc, ray, any, hit, stk, cnt);
+    else pt_trace_flat<STATS>(sc, ray, any, hit, stk, cnt);
+}
+
+__device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCounters& c) {
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&c);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+    for (unsigned i = 0; i < sizeof(PtCounters) / sizeof(unsigned long long); i++)
+        if (s[i]) atomicAdd(d + i, s[i]);
+}
+
+template <int MODE, bool STATS>
+__global__ void __launch_bounds__(PT_BLOCK) pt_render_kernel(PtRenderArgs a) {
+    extern __shared__ uint32_t pt_lds[];
+    PtStack stk;
+    stk.base = pt_lds + threadIdx.x;
+    stk.stride = PT_BLOCK;
+    stk.cap = a.scene.stack_cap;
+    const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    PtFrameRef fr;
+    fr.base = a.frames + lane_global;
+    fr.n_lanes = a.n_lanes;
+
+    PtCounters cnt;
+    if (STATS) memset(&cnt, 0, sizeof cnt);
+    PtLane L;
+    L.work = PT_IDLE; L.has_ray = false; L.ray_any = false;
+    L.x = L.y = L.sample = L.stage = L.light = L.draw = 0; L.depth = 0;
+    L.sum = pt_v3(0.0, 0.0, 0.0);
+    L.ray.o = L.ray.d = pt_v3(0.0, 0.0, 0.0);
+    PtHit hit;
+    hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        // hand out pixels to idle lanes: one atomic per wavefront
+        bool need = L.work == PT_IDLE && !exhausted;
+        unsigned long long mask = __ballot(need);
+        if (mask) {
+            unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(a.work_counter, (unsigned)__popcll(mask));
+            base = __shfl(base, (int)leader);
+            if (need) {
+                unsigned w = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                if (w >= a.n_work) {
+                    exhausted = true;
+                } else {
+                    uint32_t x, y;
+                    if (pt_work_to_pixel(a, w, &x, &y)) {
+                        L.work = w; L.x = x; L.y = y; L.sample = 0; L.stage = PT_ST_NEW_SAMPLE;
+                    }
+                }
+            }
+        }
+        bool active = L.work != PT_IDLE;
+        if (!__any(active || !exhausted)) break;
+        if (active) pt_lane_advance<STATS>(a, L, hit, fr, &cnt);
+        if (L.work != PT_IDLE && L.has_ray) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
+    }
+    if (STATS) pt_flush_counters(a.counters, cnt);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(PT_BLOCK) pt_cast_kernel(PtSceneView sc, uint64_t n, const double* o, const double* d, int any,
+                                                          double* out_t, int32_t* out_node, int32_t* out_sub) {
+    extern __shared__ uint32_t pt_lds[];
+    PtStack stk;
+    stk.base = pt_lds + threadIdx.x;
+    stk.stride = PT_BLOCK;
+    stk.cap = sc.stack_cap;
+    uint64_t i = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    PtRay r;
+    r.o = pt_v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+    r.d = pt_v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    PtHit hit;
+    PtCounters cnt;
+    pt_trace<MODE, false>(sc, r, any != 0, hit, stk, &cnt);
+    out_t[i] = hit.node == PT_NO_HIT ? INFINITY : hit.t;
+    out_node[i] = hit.node == PT_NO_HIT ? -1 : (int32_t)hit.node;
+    out_sub[i] = hit.node == PT_NO_HIT ? -1 : (int32_t)hit.sub;
+}
+
+__global__ void pt_math_kernel(int op, uint64_t n, const double* a, const double* b, double* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (op) {
+    case 0: r = sqrt(a[i]); break;
+    case 1: r = a[i] / b[i]; break;
+    case 2: r = pow(a[i], b[i]); break;
+    case 3: r = a[i] * b[i] + a[i]; break;  // must NOT be fused (-ffp-contract=off)
+    default: r = 0.0; break;
+    }
+    out[i] = r;
+}
+
+__global__ void __launch_bounds__(256) pt_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// compact (rank-major, tile-major) -> row-major image
+__global__ void pt_untile_kernel(PtRenderArgs a, uint32_t slots_per_rank, const uint8_t* gathered, uint8_t* rgb) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t total = slots_per_rank * a.tile_ranks;
+    if (i >= total) return;
+    PtRenderArgs r = a;
+    r.tile_rank = i / slots_per_rank;
+    uint32_t w = i % slots_per_rank, x, y;
+    if (!pt_work_to_pixel(r, w, &x, &y)) return;
+    const uint8_t* s = gathered + 3 * (size_t)i;
+    uint8_t* d = rgb + 3 * ((size_t)y * a.width + x);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Context
+// ------------------------------------------------------------------------------------------------
+struct PtBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct pt_context {
+    int device = 0;
+    int n_cu = 0;
+    std::string err;
+    PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh_items, kd, kd_items;
+    PtBuf frames, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
+    PtSceneView view;
+    bool have_scene = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool pending = false;
+    bool pending_stats = false;
+    std::chrono::steady_clock::time_point t_start;
+};
+
+static int pt_fail(pt_context* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define PT_HIP(c, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) return pt_fail(c, PT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static int pt_reserve(pt_context* c, PtBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return PT_OK;
+    if (b.p) { PT_HIP(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    PT_HIP(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return PT_OK;
+}
+template <class T>
+static int pt_upload(pt_context* c, PtBuf& b, const std::vector<T>& v) {
+    int rc = pt_reserve(c, b, v.size() * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) PT_HIP(c, hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+extern "C" int pt_abi_version(void) { return PT_ABI_VERSION; }
+
+extern "C" int pt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int pt_context_create(int device, pt_context** out) {
+    if (!out) return PT_ERR_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PT_ERR_DEVICE;
+    pt_context* c = new pt_context();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return PT_ERR_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return PT_ERR_DEVICE; }
+    c->n_cu = prop.multiProcessorCount;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return PT_ERR_DEVICE; }
+    memset(&c->view, 0, sizeof c->view);
+    *out = c;
+    return PT_OK;
+}
+
+extern "C" void pt_context_destroy(pt_context* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
+                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->frames, &c->bg, &c->rgb, &c->linear, &c->misc};
+    for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    delete c;
+}
+
+extern "C" const char* pt_last_error(const pt_context* c) { return c ? c->err.c_str() : "no context"; }
+
+// ------------------------------------------------------------------------------------------------
+// Scene upload
+// ------------------------------------------------------------------------------------------------
+static void pt_transform_box(const double* m, const double lo[3], const double hi[3], PtBuildBox* out) {
+    *out = pt_bvh_detail::empty_box();
+    for (int ix = 0; ix < 2; ix++) for (int iy = 0; iy < 2; iy++) for (int iz = 0; iz < 2; iz++) {
+        double x = ix ? hi[0] : lo[0], y = iy ? hi[1] : lo[1], z = iz ? hi[2] : lo[2];
+        for (int r = 0; r < 3; r++) {
+            double v = m[4 * r] * x + m[4 * r + 1] * y + m[4 * r + 2] * z + m[4 * r + 3];
+            out->lo[r] = std::min(out->lo[r], v);
+            out->hi[r] = std::max(out->hi[r], v);
+        }
+    }
+}
+static void pt_pad_box(PtBuildBox* b, double rel) {
+    for (int k = 0; k < 3; k++) {
+        double mag = std::max(std::fabs(b->lo[k]), std::fabs(b->hi[k]));
+        double pad = rel * std::max(b->hi[k] - b->lo[k], mag) + 1e-300;
+        b->lo[k] -= pad; b->hi[k] += pad;
+    }
+}
+
+extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, const pt_kdtree* kd) {
+    if (!c || !s) return PT_ERR_ARGUMENT;
+    if (traverse != PT_TRAVERSE_FLAT && traverse != PT_TRAVERSE_KD) return pt_fail(c, PT_ERR_ARGUMENT, "traverse must be PT_TRAVERSE_FLAT or PT_TRAVERSE_KD");
+    if (traverse == PT_TRAVERSE_KD && !kd) return pt_fail(c, PT_ERR_ARGUMENT, "PT_TRAVERSE_KD needs the host-built k-d tree");
+    if (s->n_nodes && (!s->trans || !s->invtrans || !s->normal_trans || !s->prim_type || !s->prim_data || !s->prim_flags || !s->material))
+        return pt_fail(c, PT_ERR_ARGUMENT, "null node array");
+    PT_HIP(c, hipSetDevice(c->device));
+    c->have_scene = false;
+    const uint32_t n = s->n_nodes;
+
+    // ---- triangles: every mesh expanded to 72-byte vertex records, stand-alone triangles appended
+    std::vector<uint64_t> tri_first(s->n_meshes + 1, 0);
+    size_t mesh_tris = s->n_meshes ? (size_t)s->mesh_tri_off[s->n_meshes] : 0;
+    size_t total_tris = mesh_tris + s->n_triangles;
+    bool any_normals = false;
+    for (uint32_t i = 0; i < n; i++) {
+        int t = s->prim_type[i];
+        if (t < PT_PRIM_SPHERE || t > PT_PRIM_CONE) return pt_fail(c, PT_ERR_ARGUMENT, "unknown primitive type");
+        if (s->material[i] < 0 || (uint32_t)s->material[i] >= s->n_materials) return pt_fail(c, PT_ERR_ARGUMENT, "material index out of range");
+        if (t == PT_PRIM_MESH || t == PT_PRIM_KDMESH) {
+            if (s->prim_data[i] < 0 || (uint32_t)s->prim_data[i] >= s->n_meshes) return pt_fail(c, PT_ERR_ARGUMENT, "mesh index out of range");
+            if (s->prim_flags[i] & 1) {
+                if (!s->mesh_has_normals || !s->mesh_has_normals[s->prim_data[i]] || !s->mesh_normals)
+                    return pt_fail(c, PT_ERR_SCENE, "smooth shading needs a vertex normal per vertex (mesh.rs:135-138)");
+                any_normals = true;
+            }
+        } else if (t == PT_PRIM_TRIANGLE) {
+            if (s->prim_data[i] < 0 || (uint32_t)s->prim_data[i] >= s->n_triangles) return pt_fail(c, PT_ERR_ARGUMENT, "triangle index out of range");
+            if (s->prim_flags[i] & 1) { if (!s->tri_normals) return pt_fail(c, PT_ERR_SCENE, "triangle normals missing"); any_normals = true; }
+        }
+    }
+    std::vector<double> tri_v(total_tris * 9), tri_n(any_normals ? total_tris * 9 : 0);
+    std::vector<PtMeshInfo> meshes(s->n_meshes);
+    std::vector<PtBvhNode> bvh;
+    std::vector<uint32_t> items;
+    std::vector<PtBuildBox> mesh_box(s->n_meshes);
+    int max_blas_depth = 0;
+    for (uint32_t m = 0; m < s->n_meshes; m++) {
+        uint64_t v0 = s->mesh_vert_off[m], v1 = s->mesh_vert_off[m + 1], t0 = s->mesh_tri_off[m], t1 = s->mesh_tri_off[m + 1];
+        if (v1 <= v0) return pt_fail(c, PT_ERR_SCENE, "meshes must have at least one vertex (mesh.rs:71)");
+        const double* pos = s->mesh_positions + 3 * v0;
+        const double* nrm = (s->mesh_normals && s->mesh_has_normals && s->mesh_has_normals[m]) ? s->mesh_normals + 3 * v0 : nullptr;
+        PtBuildBox mb = pt_bvh_detail::empty_box();
+        for (uint64_t v = 0; v < v1 - v0; v++)
+            for (int k = 0; k < 3; k++) { mb.lo[k] = std::min(mb.lo[k], pos[3 * v + k]); mb.hi[k] = std::max(mb.hi[k], pos[3 * v + k]); }
+        double ext = std::max(std::max(mb.hi[0] - mb.lo[0], mb.hi[1] - mb.lo[1]), std::max(mb.hi[2] - mb.lo[2], 1e-30));
+        std::vector<PtBuildBox> boxes(t1 - t0);
+        std::vector<uint32_t> ids(t1 - t0);
+        for (uint64_t t = t0; t < t1; t++) {
+            PtBuildBox b = pt_bvh_detail::empty_box();
+            for (int corner = 0; corner < 3; corner++) {
+                uint32_t vi = s->mesh_indices[3 * t + corner];
+                if (vi >= v1 - v0) return pt_fail(c, PT_ERR_ARGUMENT, "mesh index out of range");
+                for (int k = 0; k < 3; k++) {
+                    double x = pos[3 * (size_t)vi + k];
+                    tri_v[9 * t + 3 * corner + k] = x;
+                    if (any_normals) tri_n[9 * t + 3 * corner + k] = nrm ? nrm[3 * (size_t)vi + k] : 0.0;
+                    b.lo[k] = std::min(b.lo[k], x); b.hi[k] = std::max(b.hi[k], x);
+                }
+            }
+            for (int k = 0; k < 3; k++) { b.lo[k] -= 1e-7 * ext; b.hi[k] += 1e-7 * ext; }
+            boxes[t - t0] = b;
+            ids[t - t0] = (uint32_t)t;
+        }
+        PtBvhRef ref = pt_bvh_build(boxes.data(), ids.data(), boxes.size(), 4, bvh, items);
+        max_blas_depth = std::max(max_blas_depth, ref.depth);
+        PtMeshInfo& mi = meshes[m];
+        for (int r = 0; r < 12; r++) mi.bbox_inv[r] = s->mesh_bounds_invtrans ? s->mesh_bounds_invtrans[16 * (size_t)m + r] : 0.0;
+        if (!s->mesh_bounds_invtrans) return pt_fail(c, PT_ERR_ARGUMENT, "mesh_bounds_invtrans missing");
+        mi.tri_first = (uint32_t)t0; mi.tri_count = (uint32_t)(t1 - t0);
+        mi.blas_root = ref.child; mi.blas_root_count = ref.count;
+        for (int k = 0; k < 3; k++) { mb.lo[k] -= 1e-5 * ext; mb.hi[k] += 1e-5 * ext; }
+        mesh_box[m] = mb;
+    }
+    for (uint32_t t = 0; t < s->n_triangles; t++)
+        for (int k = 0; k < 9; k++) {
+            tri_v[9 * (mesh_tris + t) + k] = s->tri_vertices[9 * (size_t)t + k];
+            if (any_normals) tri_n[9 * (mesh_tris + t) + k] = s->tri_normals ? s->tri_normals[9 * (size_t)t + k] : 0.0;
+        }
+
+    // ---- nodes
+    std::vector<double> inv(12 * (size_t)n), fwd(12 * (size_t)n), nrm(9 * (size_t)n);
+    std::vector<uint32_t> info(4 * (size_t)n);
+    std::vector<PtBuildBox> node_box(n);
+    for (uint32_t i = 0; i < n; i++) {
+        for (int r = 0; r < 12; r++) { inv[12 * (size_t)i + r] = s->invtrans[16 * (size_t)i + r]; fwd[12 * (size_t)i + r] = s->trans[16 * (size_t)i + r]; }
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) nrm[9 * (size_t)i + 3 * r + k] = s->normal_trans[16 * (size_t)i + 4 * r + k];
+        int t = s->prim_type[i];
+        uint32_t data = (uint32_t)s->prim_data[i];
+        if (t == PT_PRIM_TRIANGLE) data = (uint32_t)(mesh_tris + data);
+        info[4 * (size_t)i] = (uint32_t)t; info[4 * (size_t)i + 1] = data;
+        info[4 * (size_t)i + 2] = (uint32_t)s->prim_flags[i]; info[4 * (size_t)i + 3] = (uint32_t)s->material[i];
+        // conservative model-space box: every hit the primitive tests can accept lies inside it
+        // (cube.rs:25 / plane.rs:31 accept points up to 1e-5 outside the unit shape)
+        double lo[3], hi[3];
+        switch (t) {
+        case PT_PRIM_SPHERE: lo[0] = lo[1] = lo[2] = -1.0001; hi[0] = hi[1] = hi[2] = 1.0001; break;
+        case PT_PRIM_PLANE: lo[0] = lo[2] = -0.5001; hi[0] = hi[2] = 0.5001; lo[1] = -1e-4; hi[1] = 1e-4; break;
+        case PT_PRIM_MESH: case PT_PRIM_KDMESH: for (int k = 0; k < 3; k++) { lo[k] = mesh_box[data].lo[k]; hi[k] = mesh_box[data].hi[k]; } break;
+        case PT_PRIM_TRIANGLE: {
+            const double* v = &tri_v[9 * (size_t)data];
+            double ext = 1e-30;
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::min(v[k], std::min(v[3 + k], v[6 + k])); hi[k] = std::max(v[k], std::max(v[3 + k], v[6 + k]));
+                ext = std::max(ext, hi[k] - lo[k]);
+            }
+            for (int k = 0; k < 3; k++) { lo[k] -= 1e-6 * ext; hi[k] += 1e-6 * ext; }
+            break;
+        }
+        default: lo[0] = lo[1] = lo[2] = -0.5001; hi[0] = hi[1] = hi[2] = 0.5001; break;  // cube, cylinder, cone
+        }
+        pt_transform_box(&s->trans[16 * (size_t)i], lo, hi, &node_box[i]);
+        pt_pad_box(&node_box[i], 1e-9);
+    }
+    PtBvhRef tlas = pt_bvh_build(node_box.data(), nullptr, n, 2, bvh, items);
+
+    // ---- k-d tree (reference structure, KD mode)
+    std::vector<PtKdNode> kdn;
+    std::vector<uint32_t> kdi;
+    double kd_extent = 0.0;
+    int kd_depth = 0;
+    if (traverse == PT_TRAVERSE_KD) {
+        if (kd->n_nodes == 0 || !kd->axis || !kd->plane || !kd->front || !kd->back || !kd->first || !kd->count || (kd->n_items && !kd->leaf_items))
+            return pt_fail(c, PT_ERR_ARGUMENT, "incomplete k-d tree");
+        kdn.resize(kd->n_nodes);
+        for (uint32_t i = 0; i < kd->n_nodes; i++) {
+            PtKdNode& k = kdn[i];
+            k.axis = kd->axis[i]; k.plane = kd->plane[i]; k.front = kd->front[i]; k.back = kd->back[i];
+            k.first = kd->first[i]; k.count = kd->count[i]; k.pad = 0;
+            if (k.axis >= 0) {
+                if (k.axis > 2 || k.front < 0 || k.back < 0 || (uint32_t)k.front >= kd->n_nodes || (uint32_t)k.back >= kd->n_nodes)
+                    return pt_fail(c, PT_ERR_ARGUMENT, "k-d child out of range");
+            } else if (k.first < 0 || k.count < 0 || (uint32_t)(k.first + k.count) > kd->n_items) {
+                return pt_fail(c, PT_ERR_ARGUMENT, "k-d leaf range out of bounds");
+            }
+        }
+        kdi.resize(kd->n_items);
+        for (uint32_t i = 0; i < kd->n_items; i++) {
+            if (kd->leaf_items[i] < 0 || (uint32_t)kd->leaf_items[i] >= n) return pt_fail(c, PT_ERR_ARGUMENT, "k-d leaf item out of range");
+            kdi[i] = (uint32_t)kd->leaf_items[i];
+        }
+        double dx = kd->root_max[0] - kd->root_min[0], dy = kd->root_max[1] - kd->root_min[1], dz = kd->root_max[2] - kd->root_min[2];
+        kd_extent = (dx * dx + dy * dy) + dz * dz;  // bounding_box.rs:95-99 magnitude_squared
+        kd_depth = kd->max_depth < 0 ? 0 : kd->max_depth;
+    }
+
+    int rc;
+    if ((rc = pt_upload(c, c->inv, inv)) || (rc = pt_upload(c, c->fwd, fwd)) || (rc = pt_upload(c, c->nrm, nrm)) ||
+        (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_v, tri_v)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
+        (rc = pt_upload(c, c->meshes, meshes)) || (rc = pt_upload(c, c->bvh, bvh)) || (rc = pt_upload(c, c->bvh_items, items)) ||
+        (rc = pt_upload(c, c->kd, kdn)) || (rc = pt_upload(c, c->kd_items, kdi)))
+        return rc;
+    std::vector<double> mats(s->materials, s->materials + 10 * (size_t)s->n_materials);
+    std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
+    if ((rc = pt_upload(c, c->materials, mats)) || (rc = pt_upload(c, c->lights, lights))) return rc;
+
+    PtSceneView& v = c->view;
+    memset(&v, 0, sizeof v);
+    v.n_nodes = n; v.n_lights = s->n_lights;
+    v.inv = (const double*)c->inv.p; v.fwd = (const double*)c->fwd.p; v.nrm = (const double*)c->nrm.p;
+    v.info = (const uint32_t*)c->info.p; v.tri_v = (const double*)c->tri_v.p; v.tri_n = (const double*)c->tri_n.p;
+    v.meshes = (const PtMeshInfo*)c->meshes.p; v.materials = (const double*)c->materials.p; v.lights = (const double*)c->lights.p;
+    for (int k = 0; k < 3; k++) v.ambient[k] = s->ambient[k];
+    v.bvh = (const PtBvhNode*)c->bvh.p; v.bvh_items = (const uint32_t*)c->bvh_items.p;
+    v.tlas_root = tlas.child; v.tlas_root_count = tlas.count;
+    v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
+    v.kd_extent = kd_extent;
+    v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : PT_MODE_FLAT;
+    int cap = traverse == PT_TRAVERSE_KD ? 5 * (kd_depth + 1) + 2 * max_blas_depth + 4 : 2 * (tlas.depth + max_blas_depth) + 4;
+    v.stack_cap = std::max(cap, 8);
+    if ((size_t)v.stack_cap * PT_BLOCK * 4 > 64 * 1024) return pt_fail(c, PT_ERR_SCENE, "traversal stack would not fit in LDS (tree too deep)");
+    c->have_scene = true;
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Render
+// ------------------------------------------------------------------------------------------------
+static uint32_t pt_slots_per_rank(const pt_render_params* p) {
+    uint32_t rw = p->slice.x1 - p->slice.x0 + 1, rh = p->slice.y1 - p->slice.y0 + 1;
+    uint32_t tiles = ((rw + 7) / 8) * ((rh + 7) / 8);
+    uint32_t ranks = p->tile_ranks ? p->tile_ranks : 1;
+    return ((tiles + ranks - 1) / ranks) * 64;
+}
+
+extern "C" uint64_t pt_compact_bytes(const pt_render_params* p) {
+    if (!p || p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0) return 0;
+    return 3ull * pt_slots_per_rank(p);
+}
+
+static int pt_check_params(pt_context* c, const pt_camera* cam, const pt_render_params* p) {
+    if (!c || !cam || !p) return PT_ERR_ARGUMENT;
+    if (!c->have_scene) return pt_fail(c, PT_ERR_NO_SCENE, "no scene uploaded");
+    if (p->width == 0 || p->height == 0 || p->samples == 0) return pt_fail(c, PT_ERR_ARGUMENT, "width, height and samples must be positive");
+    if (p->slice.x0 >= p->width || p->slice.x1 >= p->width || p->slice.y0 >= p->height || p->slice.y1 >= p->height)
+        return pt_fail(c, PT_ERR_SLICE, "slice corner outside the image (render.rs:79-90)");
+    if (p->tile_ranks == 0 || p->tile_rank >= p->tile_ranks) return pt_fail(c, PT_ERR_ARGUMENT, "tile_rank must be < tile_ranks");
+    if (p->sample_mode != PT_SAMPLE_CENTRE && p->sample_mode != PT_SAMPLE_RNG) return pt_fail(c, PT_ERR_ARGUMENT, "bad sample_mode");
+    return PT_OK;
+}
+
+template <int MODE, bool STATS>
+static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
+    size_t lds = (size_t)a.scene.stack_cap * PT_BLOCK * 4;
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS>, PT_BLOCK, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    uint32_t want = (a.n_work + PT_BLOCK - 1) / PT_BLOCK;
+    uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
+    *grid_out = grid;
+    if (!launch) return hipSuccess;
+    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
+    return hipGetLastError();
+}
+
+static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
+    if (a.scene.mode == PT_MODE_KD) return stats ? pt_launch<PT_MODE_KD, true>(a, n_cu, stream, grid, launch) : pt_launch<PT_MODE_KD, false>(a, n_cu, stream, grid, launch);
+    return stats ? pt_launch<PT_MODE_FLAT, true>(a, n_cu, stream, grid, launch) : pt_launch<PT_MODE_FLAT, false>(a, n_cu, stream, grid, launch);
+}
+
+static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_params* p, PtRenderArgs* a) {
+    memset(a, 0, sizeof *a);
+    a->scene = c->view;
+    for (int k = 0; k < 3; k++) a->cam.eye[k] = cam->eye[k];
+    for (int k = 0; k < 12; k++) a->cam.view_to_world[k] = cam->view_to_world[k];
+    a->cam.fov_factor = cam->fov_factor; a->cam.aspect = cam->aspect_ratio; a->cam.width = cam->width; a->cam.height = cam->height;
+    a->background_rows = p->background_rows;
+    a->width = p->width; a->height = p->height;
+    a->x0 = p->slice.x0; a->y0 = p->slice.y0; a->x1 = p->slice.x1; a->y1 = p->slice.y1;
+    a->samples = p->samples; a->seed = p->seed; a->jitter_mode = p->sample_mode;
+    a->tile_rank = p->tile_rank; a->tile_ranks = p->tile_ranks;
+    bool empty = p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0;  // render.rs:60-65: an inverted slice renders nothing
+    a->n_work = empty ? 0 : pt_slots_per_rank(p);
+    return PT_OK;
+}
+
+static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStream_t stream) {
+    uint32_t grid = 0;
+    PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
+    a.n_lanes = grid * PT_BLOCK;
+    int rc = pt_reserve(c, c->frames, (size_t)a.n_lanes * (PT_MAX_DEPTH + 1) * PT_FRAME_SLOTS * sizeof(double));
+    if (rc) return rc;
+    if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters)))) return rc;
+    a.frames = (double*)c->frames.p;
+    a.work_counter = (unsigned int*)c->misc.p;
+    a.counters = (PtCounters*)((char*)c->misc.p + 256);
+    PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters), stream));
+    PT_HIP(c, hipEventRecord(c->ev0, stream));
+    if (a.n_work) PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, true));
+    PT_HIP(c, hipEventRecord(c->ev1, stream));
+    return PT_OK;
+}
+
+static int pt_collect_stats(pt_context* c, pt_stats* st, bool counted) {
+    if (!st) return PT_OK;
+    memset(st, 0, sizeof *st);
+    float ms = 0.f;
+    PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    st->kernel_ms = ms;
+    PtCounters h;
+    PT_HIP(c, hipMemcpy(&h, (char*)c->misc.p + 256, sizeof h, hipMemcpyDeviceToHost));
+    if (counted) {
+        st->primary = h.primary; st->shadow = h.shadow; st->reflect = h.reflect; st->refract = h.refract;
+        st->depth11_skipped = h.depth11_skipped; st->hits = h.hits; st->n_inner = h.n_inner; st->n_leaf = h.n_leaf;
+        st->n_analytic = h.n_analytic; st->n_tri = h.n_tri; st->n_bbox = h.n_bbox; st->kd_plane_miss = h.kd_plane_miss;
+        st->stack_overflow = h.stack_overflow;
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_render(pt_context* c, const pt_camera* cam, const double* background, const pt_render_params* p,
+                         uint8_t* rgb, double* linear, pt_stats* stats) {
+    int rc = pt_check_params(c, cam, p);
+    if (rc) return rc;
+    if (!background || !rgb) return pt_fail(c, PT_ERR_ARGUMENT, "background and rgb must not be null");
+    PT_HIP(c, hipSetDevice(c->device));
+    auto t0 = std::chrono::steady_clock::now();
+    PtRenderArgs a;
+    pt_fill_args(c, cam, p, &a);
+    size_t px = (size_t)p->width * p->height;
+    size_t bg_bytes = (p->background_rows ? (size_t)p->height : px) * 3 * sizeof(double);
+    if ((rc = pt_reserve(c, c->bg, bg_bytes)) || (rc = pt_reserve(c, c->rgb, px * 3))) return rc;
+    if (linear && (rc = pt_reserve(c, c->linear, px * 3 * sizeof(double)))) return rc;
+    PT_HIP(c, hipMemcpy(c->bg.p, background, bg_bytes, hipMemcpyHostToDevice));
+    // pixels outside the slice / of other ranks keep the caller's bytes (render.rs:135-138)
+    PT_HIP(c, hipMemcpy(c->rgb.p, rgb, px * 3, hipMemcpyHostToDevice));
+    if (linear) PT_HIP(c, hipMemcpy(c->linear.p, linear, px * 3 * sizeof(double), hipMemcpyHostToDevice));
+    a.background = (const double*)c->bg.p;
+    a.compact = 0;
+    a.rgb = (uint8_t*)c->rgb.p;
+    a.linear = linear ? (double*)c->linear.p : nullptr;
+    bool counted = p->collect_stats != 0;
+    if ((rc = pt_render_common(c, a, counted, nullptr))) return rc;
+    PT_HIP(c, hipDeviceSynchronize());
+    PT_HIP(c, hipMemcpy(rgb, c->rgb.p, px * 3, hipMemcpyDeviceToHost));
+    if (linear) PT_HIP(c, hipMemcpy(linear, c->linear.p, px * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if ((rc = pt_collect_stats(c, stats, counted))) return rc;
+    if (stats) {
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (stats->stack_overflow) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_render_device(pt_context* c, const pt_camera* cam, const double* d_background, const pt_render_params* p,
+                                int compact, void* d_rgb, void* hip_stream) {
+    int rc = pt_check_params(c, cam, p);
+    if (rc) return rc;
+    if (!d_background || !d_rgb) return pt_fail(c, PT_ERR_ARGUMENT, "d_background and d_rgb must not be null");
+    PT_HIP(c, hipSetDevice(c->device));
+    PtRenderArgs a;
+    pt_fill_args(c, cam, p, &a);
+    a.background = d_background;
+    a.compact = compact ? 1 : 0;
+    a.rgb = (uint8_t*)d_rgb;
+    a.linear = nullptr;
+    c->pending_stats = p->collect_stats != 0;
+    c->t_start = std::chrono::steady_clock::now();
+    if ((rc = pt_render_common(c, a, c->pending_stats, (hipStream_t)hip_stream))) return rc;
+    c->pending = true;
+    return PT_OK;
+}
+
+extern "C" int pt_render_finish(pt_context* c, pt_stats* stats) {
+    if (!c) return PT_ERR_ARGUMENT;
+    if (!c->pending) return pt_fail(c, PT_ERR_ARGUMENT, "no render in flight");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipEventSynchronize(c->ev1));
+    c->pending = false;
+    int rc = pt_collect_stats(c, stats, c->pending_stats);
+    if (rc) return rc;
+    if (stats) {
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->t_start).count();
+        if (stats->stack_overflow) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_untile_device(pt_context* c, const pt_render_params* p, const void* d_gathered, void* d_rgb, void* hip_stream) {
+    if (!c || !p || !d_gathered || !d_rgb) return PT_ERR_ARGUMENT;
+    if (p->width == 0 || p->height == 0 || p->tile_ranks == 0) return pt_fail(c, PT_ERR_ARGUMENT, "bad params");
+    if (p->slice.x0 >= p->width || p->slice.x1 >= p->width || p->slice.y0 >= p->height || p->slice.y1 >= p->height)
+        return pt_fail(c, PT_ERR_SLICE, "slice corner outside the image (render.rs:79-90)");
+    if (p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    PtRenderArgs a;
+    memset(&a, 0, sizeof a);
+    a.width = p->width; a.height = p->height;
+    a.x0 = p->slice.x0; a.y0 = p->slice.y0; a.x1 = p->slice.x1; a.y1 = p->slice.y1;
+    a.tile_ranks = p->tile_ranks;
+    uint32_t per = pt_slots_per_rank(p);
+    uint32_t total = per * p->tile_ranks;
+    hipLaunchKernelGGL(pt_untile_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, a, per, (const uint8_t*)d_gathered, (uint8_t*)d_rgb);
+    PT_HIP(c, hipGetLastError());
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Harness helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int pt_device_alloc(pt_context* c, uint64_t bytes, void** out) {
+    if (!c || !out) return PT_ERR_ARGUMENT;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipMalloc(out, bytes ? bytes : 16));
+    return PT_OK;
+}
+extern "C" int pt_device_free(pt_context* c, void* p) {
+    if (!c) return PT_ERR_ARGUMENT;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipFree(p));
+    return PT_OK;
+}
+extern "C" int pt_copy_to_device(pt_context* c, void* dst, const void* src, uint64_t bytes) {
+    if (!c) return PT_ERR_ARGUMENT;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PT_OK;
+}
+extern "C" int pt_copy_from_device(pt_context* c, void* dst, const void* src, uint64_t bytes) {
+    if (!c) return PT_ERR_ARGUMENT;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+extern "C" int pt_measure_copy_bandwidth(pt_context* c, uint64_t bytes, int iters, double* gbps) {
+    if (!c || !gbps || bytes < 16) return PT_ERR_ARGUMENT;
+    PT_HIP(c, hipSetDevice(c->device));
+    void *src = nullptr, *dst = nullptr;
+    PT_HIP(c, hipMalloc(&src, bytes));
+    PT_HIP(c, hipMalloc(&dst, bytes));
+    PT_HIP(c, hipMemset(src, 1, bytes));
+    size_t n = bytes / 16;
+    double best = 0.0;
+    for (int i = 0; i < iters + 1; i++) {
+        PT_HIP(c, hipEventRecord(c->ev0, nullptr));
+        hipLaunchKernelGGL(pt_copy_kernel, dim3(c->n_cu * 8), dim3(256), 0, nullptr, (const double2*)src, (double2*)dst, n);
+        PT_HIP(c, hipEventRecord(c->ev1, nullptr));
+        PT_HIP(c, hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        if (i > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)(n * 16) / (ms * 1e-3) / 1e9);
+    }
+    hipFree(src); hipFree(dst);
+    *gbps = best;
+    return PT_OK;
+}
+
+extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origins, const double* directions, int any_hit,
+                                 double* out_t, int32_t* out_node, int32_t* out_sub) {
+    if (!c || !origins || !directions || !out_t || !out_node || !out_sub) return PT_ERR_ARGUMENT;
+    if (!c->have_scene) return pt_fail(c, PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    double *d_o, *d_d, *d_t; int32_t *d_n, *d_s;
+    PT_HIP(c, hipMalloc((void**)&d_o, n * 24)); PT_HIP(c, hipMalloc((void**)&d_d, n * 24)); PT_HIP(c, hipMalloc((void**)&d_t, n * 8));
+    PT_HIP(c, hipMalloc((void**)&d_n, n * 4)); PT_HIP(c, hipMalloc((void**)&d_s, n * 4));
+    PT_HIP(c, hipMemcpy(d_o, origins, n * 24, hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(d_d, directions, n * 24, hipMemcpyHostToDevice));
+    size_t lds = (size_t)c->view.stack_cap * PT_BLOCK * 4;
+    dim3 grid((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK));
+    if (c->view.mode == PT_MODE_KD) hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_KD>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
+    else hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_FLAT>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
+    PT_HIP(c, hipGetLastError());
+    PT_HIP(c, hipDeviceSynchronize());
+    PT_HIP(c, hipMemcpy(out_t, d_t, n * 8, hipMemcpyDeviceToHost));
+    PT_HIP(c, hipMemcpy(out_node, d_n, n * 4, hipMemcpyDeviceToHost));
+    PT_HIP(c, hipMemcpy(out_sub, d_s, n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_n); hipFree(d_s);
+    return PT_OK;
+}
+
+extern "C" int pt_test_math(pt_context* c, int op, uint64_t n, const double* a, const double* b, double* out) {
+    if (!c || !a || !b || !out) return PT_ERR_ARGUMENT;
+    if (n == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    double *d_a, *d_b, *d_o;
+    PT_HIP(c, hipMalloc((void**)&d_a, n * 8)); PT_HIP(c, hipMalloc((void**)&d_b, n * 8)); PT_HIP(c, hipMalloc((void**)&d_o, n * 8));
+    PT_HIP(c, hipMemcpy(d_a, a, n * 8, hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(d_b, b, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pt_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n, d_a, d_b, d_o);
+    PT_HIP(c, hipGetLastError());
+    PT_HIP(c, hipDeviceSynchronize());
+    PT_HIP(c, hipMemcpy(out, d_o, n * 8, hipMemcpyDeviceToHost));
+    hipFree(d_a); hipFree(d_b); hipFree(d_o);
+    return PT_OK;
+}

@@ -1,0 +1,76 @@
+// Device-resident scene layout (what pt_scene_upload builds in HBM) as seen by the kernels.
+//
+// All buffers are structure-of-arrays, read-only during a render, sized for residency (a scene is
+// uploaded once per pt_scene_upload and stays in HBM / L2 across renders):
+//   inv  : n_nodes x 12 f64  rows 0..2 of invtrans      (flat_scene.rs:50-61; read per candidate test)
+//   fwd  : n_nodes x 12 f64  rows 0..2 of trans         (read once per shaded hit)
+//   nrm  : n_nodes x  9 f64  upper 3x3 of normal_trans  (read once per shaded hit)
+//   info : n_nodes x  4 u32  {prim type, prim data, flags, material}
+//   tri_v: n_tris  x  9 f64  a, b, c per triangle, 72-byte records (mesh.rs:97-115 expanded once)
+//   tri_n: n_tris  x  9 f64  vertex normals (smooth shading only)
+//   materials: x 10 f64, lights: x 15 f64
+//   bvh / bvh_items: the build's own acceleration structure for FLAT mode (two levels: one tree over
+//          the flattened nodes in world space, one tree per mesh in model space)
+//   kd / kd_items: the reference's scene k-d tree, linearised (kdtree/node.rs:13-25), for KD mode
+#pragma once
+
+#include "pt_math.h"
+
+enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2 };
+
+// Two children per record so one fetch decides both sides. child >= 0: inner node index;
+// child < 0: leaf, items[first .. first+count) with first = ~child.
+struct PtBvhNode {
+    double lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t count0, count1;
+};  // 112 bytes
+
+struct PtKdNode {
+    double plane;          // coordinate of the separating plane on `axis`
+    int32_t axis;          // 0..2, or -1 for a leaf
+    int32_t front, back;   // children (node.rs:20-22)
+    int32_t first, count;  // leaf: kd_items[first .. first+count)
+    int32_t pad;
+};  // 32 bytes
+
+struct PtMeshInfo {
+    double bbox_inv[12];   // rows 0..2 of BoundingBox::invtrans (bounding_box.rs:55-82)
+    uint32_t tri_first, tri_count;
+    int32_t blas_root;     // encoded like PtBvhNode::child (may be a leaf)
+    int32_t blas_root_count;
+};
+
+struct PtSceneView {
+    uint32_t n_nodes, n_lights;
+    const double* inv;
+    const double* fwd;
+    const double* nrm;
+    const uint32_t* info;
+    const double* tri_v;
+    const double* tri_n;
+    const PtMeshInfo* meshes;
+    const double* materials;
+    const double* lights;
+    double ambient[3];
+    const PtBvhNode* bvh;
+    const uint32_t* bvh_items;
+    int32_t tlas_root, tlas_root_count;
+    const PtKdNode* kd;
+    const uint32_t* kd_items;
+    double kd_extent;  // bounding_box.rs:95-99: squared diagonal of the root bounds
+    int32_t mode;
+    int32_t stack_cap;  // entries per lane in the traversal stack
+};
+
+struct PtCamera {  // camera.rs:17-31, built on the host (look_at inverse, tan)
+    double eye[3];
+    double view_to_world[12];  // rows 0..2
+    double fov_factor, aspect, width, height;
+};
+
+// Per-lane counters, SURVEY §8(d) ray accounting
+struct PtCounters {
+    unsigned long long primary, shadow, reflect, refract, depth11_skipped, hits;
+    unsigned long long n_inner, n_leaf, n_analytic, n_tri, n_bbox, kd_plane_miss, stack_overflow;
+};

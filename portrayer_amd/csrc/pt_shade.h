@@ -1,0 +1,377 @@
+// Per-lane ray state machine: primary-ray generation, Blinn-Phong + shadow rays, and the
+// reflection / refraction recursion of the reference turned into iteration.
+//
+// Replaces render_single_pixel (src/render.rs:22-51), Camera::ray_at (src/camera.rs:48-84),
+// Ray::color (src/ray.rs:139-148) and Material::hit_color (src/material.rs:91-320).
+//
+// The reference recurses: hit_color(depth) -> Ray::color(depth + 1) -> hit_color ... and folds the
+// child's colour into the parent AFTER the child returns (`color += reflectivity * child`,
+// material.rs:243,280,307-309,315). A forward "throughput" accumulation would round differently,
+// so each lane keeps an explicit stack of frames (one per depth 0..=10) in HBM and folds them back
+// in recursion order. A lane is a small interpreter: every call to pt_lane_advance() consumes the
+// result of the ray it traced last and runs until it has the NEXT ray to trace (primary, shadow,
+// reflected or refracted) — so all 64 lanes of a wavefront meet again in the traversal loop
+// whatever kind of ray each one carries.
+//
+// Frame layout in HBM, structure-of-arrays over lanes so a wavefront's accesses coalesce:
+//   slot s of depth d of lane l at frames[(d * PT_FRAME_SLOTS + s) * n_lanes + l]
+//   slots 0-2 ray direction D (later: reflected colour Cr), 3-5 hit point P (3: Schlick
+//   reflectance once the refracted ray is in flight), 6-8 unit normal N, 9-11 colour so far,
+//   12 {material, frame stage}.
+#pragma once
+
+#include "pt_trace.h"
+
+#define PT_FRAME_SLOTS 13
+#define PT_MAX_DEPTH 10  // material.rs:12
+#define PT_IDLE 0xFFFFFFFFu
+
+enum { PT_JITTER_CENTRE = 0, PT_JITTER_RNG = 1 };
+enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_AFTER_LIGHTS = 4 };
+enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2 };
+
+struct PtRenderArgs {
+    PtSceneView scene;
+    PtCamera cam;
+    const double* background;  // H x 3 (rows) or H x W x 3
+    int32_t background_rows;
+    uint32_t width, height;
+    uint32_t x0, y0, x1, y1;   // inclusive slice (render.rs:115-138)
+    uint32_t samples;
+    uint64_t seed;
+    int32_t jitter_mode;
+    uint32_t tile_rank, tile_ranks;  // this launch renders 8x8 tiles t with t % tile_ranks == tile_rank
+    uint32_t n_work;                 // pixels slots in this launch (own tiles x 64)
+    int32_t compact;                 // 1: rgb is tile-major over own tiles; 0: rgb is the full H x W x 3 image
+    uint8_t* rgb;
+    double* linear;                  // optional, same indexing as rgb
+    double* frames;
+    uint32_t n_lanes;
+    unsigned int* work_counter;
+    PtCounters* counters;
+};
+
+struct PtLane {
+    uint32_t work;  // slot index in this launch, PT_IDLE when the lane has no pixel
+    uint32_t x, y, sample, stage, light, draw;
+    int32_t depth;
+    PtVec3 sum;
+    PtRay ray;
+    bool has_ray, ray_any;
+};
+
+struct PtFrameRef {
+    double* base;
+    uint32_t n_lanes;
+    PT_HD double& at(int depth, int slot) const { return base[(size_t)(depth * PT_FRAME_SLOTS + slot) * n_lanes]; }
+    PT_HD PtVec3 load3(int depth, int slot) const { return pt_v3(at(depth, slot), at(depth, slot + 1), at(depth, slot + 2)); }
+    PT_HD void store3(int depth, int slot, PtVec3 v) const { at(depth, slot) = v.x; at(depth, slot + 1) = v.y; at(depth, slot + 2) = v.z; }
+    PT_HD void store_tag(int depth, uint32_t mat, uint32_t stage) const {
+        union { double d; uint32_t u[2]; } c; c.u[0] = mat; c.u[1] = stage; at(depth, 12) = c.d;
+    }
+    PT_HD void load_tag(int depth, uint32_t* mat, uint32_t* stage) const {
+        union { double d; uint32_t u[2]; } c; c.d = at(depth, 12); *mat = c.u[0]; *stage = c.u[1];
+    }
+};
+
+// 8x8 tiles over the slice rectangle, row-major over tiles; work slot w = local tile * 64 + j.
+PT_HD bool pt_work_to_pixel(const PtRenderArgs& a, uint32_t w, uint32_t* x, uint32_t* y) {
+    uint32_t rw = a.x1 - a.x0 + 1;
+    uint32_t tiles_x = (rw + 7) / 8;
+    uint32_t tile = (w >> 6) * a.tile_ranks + a.tile_rank;
+    uint32_t j = w & 63;
+    uint32_t px = a.x0 + (tile % tiles_x) * 8 + (j & 7);
+    uint32_t py = a.y0 + (tile / tiles_x) * 8 + (j >> 3);
+    *x = px; *y = py;
+    return px <= a.x1 && py <= a.y1;
+}
+
+PT_HD PtVec3 pt_background(const PtRenderArgs& a, uint32_t x, uint32_t y) {  // render.rs:31-34
+    const double* b = a.background_rows ? a.background + 3 * (size_t)y : a.background + 3 * ((size_t)y * a.width + x);
+    return pt_v3(b[0], b[1], b[2]);
+}
+
+PT_HD PtRay pt_camera_ray(const PtCamera& c, double x, double y) {  // camera.rs:48-84
+    double ndc_y = y / c.height;
+    double view_y = (1.0 - 2.0 * ndc_y) * c.fov_factor;
+    double ndc_x = x / c.width;
+    double view_x = (2.0 * ndc_x - 1.0) * c.aspect * c.fov_factor;
+    PtVec3 eye = pt_v3(c.eye[0], c.eye[1], c.eye[2]);
+    PtVec3 world = pt_xform_point(c.view_to_world, pt_v3(view_x, view_y, -1.0));
+    PtRay r;
+    r.o = eye;
+    r.d = pt_normalized(world - eye);
+    return r;
+}
+
+PT_HD uint8_t pt_to_u8(double c) {  // render.rs:143-147: `as u8` saturates, NaN -> 0
+    double v = c * 255.0;
+    if (!(v > 0.0)) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+
+PT_HD double pt_powi5(double x) {  // f64::powi(5): x * ((x*x) * (x*x))
+    double x2 = x * x, x4 = x2 * x2;
+    return x * x4;
+}
+
+// material.rs:27-48
+PT_HD bool pt_refracted_direction(PtVec3 ray_dir, PtVec3 normal, double eta, PtVec3* out) {
+    const double eta_outside = 1.00;
+    double c = pt_dot(ray_dir, normal);
+    double under_sqrt = 1.0 - eta_outside * eta_outside * (1.0 - c * c) / (eta * eta);
+    if (under_sqrt < 0.0) return false;
+    PtVec3 d1 = ((ray_dir - normal * c) * eta_outside) / eta;
+    PtVec3 d2 = normal * sqrt(under_sqrt);
+    *out = d1 - d2;
+    return true;
+}
+
+PT_HD void pt_finish_pixel(const PtRenderArgs& a, const PtLane& L) {  // render.rs:45-50, :143-147
+    PtVec3 color = L.sum / (double)a.samples;
+    size_t idx = a.compact ? (size_t)L.work : (size_t)L.y * a.width + L.x;
+    if (a.linear) { double* o = a.linear + 3 * idx; o[0] = color.x; o[1] = color.y; o[2] = color.z; }
+    const double g = 1.0 / PT_GAMMA;
+    double ch[3] = {pow(color.x, g), pow(color.y, g), pow(color.z, g)};
+    uint8_t* o = a.rgb + 3 * idx;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double v = ch[k];
+        v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        o[k] = pt_to_u8(v);
+    }
+}
+
+// Position of light `li` as sampled for the current hit (light.rs:62-70, :87-90). `draw0` is the
+// index of the first of the two draws an area light consumes; the generator is counter-based, so
+// re-evaluating with the same indices after the shadow ray returns yields the same point.
+PT_HD PtVec3 pt_light_position(const PtRenderArgs& a, const PtLane& L, const double* light, uint32_t draw0, bool* is_area) {
+    PtVec3 pos = pt_v3(light[0], light[1], light[2]);
+    PtVec3 aa = pt_v3(light[9], light[10], light[11]), ab = pt_v3(light[12], light[13], light[14]);
+    bool empty = (aa.x == 0.0 && aa.y == 0.0 && aa.z == 0.0) || (ab.x == 0.0 && ab.y == 0.0 && ab.z == 0.0);  // light.rs:51-53
+    *is_area = !empty;
+    if (empty) return pos;
+    uint64_t pixel = (uint64_t)L.y * a.width + L.x;
+    double a_coord = 2.0 * pt_rng_f64(a.seed, pixel, L.sample, draw0) - 1.0;
+    double b_coord = 2.0 * pt_rng_f64(a.seed, pixel, L.sample, draw0 + 1) - 1.0;
+    return pos + (aa * a_coord + ab * b_coord);
+}
+
+// Runs the lane's interpreter until it needs a ray traced (L.has_ray) or its pixel is finished
+// (L.work == PT_IDLE). `hit` is the result of the ray the lane traced last.
+template <bool STATS>
+PT_HD void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt) {
+    const PtSceneView& sc = a.scene;
+    L.has_ray = false;
+    PtVec3 value = pt_v3(0.0, 0.0, 0.0);  // colour being returned to the parent frame
+    bool returning = false;
+    for (;;) {
+        if (returning) {
+            // `value` = Ray::color() of the ray cast at depth L.depth
+            returning = false;
+            if (L.depth == 0) {  // render.rs:36-43: samples summed in ascending order
+                L.sum = L.sample == 0 ? value : L.sum + value;
+                L.sample++;
+                L.stage = PT_ST_NEW_SAMPLE;
+                continue;
+            }
+            L.depth--;
+            uint32_t mat, fstage;
+            fr.load_tag(L.depth, &mat, &fstage);
+            const double* m = sc.materials + 10 * (size_t)mat;
+            double reflectivity = m[7], ior = m[9];
+            PtVec3 color = fr.load3(L.depth, 9);
+            if (fstage == PT_FS_WAIT_REFRACT) {  // material.rs:305-309
+                PtVec3 reflected = fr.load3(L.depth, 0);
+                double schlick = fr.at(L.depth, 3);
+                double transmittance = 1.0 - schlick;
+                PtVec3 total = reflected * schlick + value * transmittance;
+                value = color + total * reflectivity;
+                returning = true;
+                continue;
+            }
+            // PT_FS_WAIT_REFLECT: `value` is reflected_color (material.rs:242-243)
+            if (!(ior > 0.0)) {  // material.rs:312-316
+                value = color + value * reflectivity;
+                returning = true;
+                continue;
+            }
+            PtVec3 ray_dir = fr.load3(L.depth, 0), P = fr.load3(L.depth, 3), N = fr.load3(L.depth, 6);
+            PtVec3 refract_dir;
+            double cos_incident = 0.0;
+            bool have = false;
+            if (pt_dot(ray_dir, N) < 0.0) {  // entering (material.rs:253-265)
+                if (pt_refracted_direction(ray_dir, N, ior, &refract_dir)) { cos_incident = pt_dot(-ray_dir, N); have = true; }
+            } else if (pt_refracted_direction(ray_dir, -N, 1.0 / ior, &refract_dir)) {  // leaving (:266-276)
+                cos_incident = pt_dot(refract_dir, N); have = true;
+            }
+            if (!have) {  // total internal reflection (:277-284); also where the reference's expect() at :257-258 would panic
+                value = color + value * reflectivity;
+                returning = true;
+                continue;
+            }
+            double r0 = (ior - 1.0) * (ior - 1.0);
+            r0 = r0 / ((ior + 1.0) * (ior + 1.0));
+            double schlick = r0 + (1.0 - r0) * pt_powi5(1.0 - cos_incident);
+            if (L.depth + 1 > PT_MAX_DEPTH) {  // the refracted ray's colour would be discarded (material.rs:102-104): background
+                if (STATS) cnt->depth11_skipped++;
+                PtVec3 bg = pt_background(a, L.x, L.y);
+                double transmittance = 1.0 - schlick;
+                PtVec3 total = value * schlick + bg * transmittance;
+                value = color + total * reflectivity;
+                returning = true;
+                continue;
+            }
+            fr.store3(L.depth, 0, value);
+            fr.at(L.depth, 3) = schlick;
+            fr.store_tag(L.depth, mat, PT_FS_WAIT_REFRACT);
+            L.ray.o = P; L.ray.d = refract_dir;
+            L.depth++;
+            L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
+            if (STATS) cnt->refract++;
+            return;
+        }
+        switch (L.stage) {
+        case PT_ST_NEW_SAMPLE: {
+            if (L.sample >= a.samples) {
+                pt_finish_pixel(a, L);
+                L.work = PT_IDLE;
+                return;
+            }
+            double jx = 0.5, jy = 0.5;
+            if (a.jitter_mode == PT_JITTER_RNG) {  // render.rs:38-39: x drawn before y
+                uint64_t pixel = (uint64_t)L.y * a.width + L.x;
+                jx = pt_rng_f64(a.seed, pixel, L.sample, 0);
+                jy = pt_rng_f64(a.seed, pixel, L.sample, 1);
+            }
+            L.draw = 2;
+            L.ray = pt_camera_ray(a.cam, (double)L.x + jx, (double)L.y + jy);
+            L.depth = 0;
+            L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
+            if (STATS) cnt->primary++;
+            return;
+        }
+        case PT_ST_CLOSEST_DONE: {  // ray.rs:139-148
+            if (hit.node == PT_NO_HIT) { value = pt_background(a, L.x, L.y); returning = true; continue; }
+            if (STATS) cnt->hits++;
+            // flat_scene.rs:85-95: rebuild the model-space hit, bring point and normal to world space
+            const uint32_t* info = sc.info + 4 * (size_t)hit.node;
+            uint32_t type = info[0], flags = info[2], mat = info[3];
+            PtRay local = pt_ray_to_local(sc.inv + 12 * (size_t)hit.node, L.ray);
+            PtVec3 p, n;
+            if (type == PT_TRIANGLE || type == PT_MESH || type == PT_KDMESH) {
+                const double* v = sc.tri_v + 9 * (size_t)hit.sub;
+                p = pt_ray_at(local, hit.t);
+                bool smooth = (flags & 1u) != 0;
+                if (smooth) {  // triangle.rs:82-86: re-derive beta / gamma with the same arithmetic
+                    double t2, beta, gamma;
+                    pt_triangle_hit(v, local, -INFINITY, INFINITY, &t2, &beta, &gamma);
+                    double alpha = 1.0 - beta - gamma;
+                    const double* vn = sc.tri_n + 9 * (size_t)hit.sub;
+                    n = (pt_v3(vn[0], vn[1], vn[2]) * alpha + pt_v3(vn[3], vn[4], vn[5]) * beta) + pt_v3(vn[6], vn[7], vn[8]) * gamma;
+                } else {       // triangle.rs:87: (b - a) x (c - a)
+                    PtVec3 A = pt_v3(v[0], v[1], v[2]), B = pt_v3(v[3], v[4], v[5]), C = pt_v3(v[6], v[7], v[8]);
+                    n = pt_cross(B - A, C - A);
+                }
+            } else {
+                pt_prim_surface(type, hit.sub, local, hit.t, &p, &n);
+            }
+            PtVec3 P = pt_xform_point(sc.fwd + 12 * (size_t)hit.node, p);
+            PtVec3 Nw = pt_xform_dir(sc.nrm + 9 * (size_t)hit.node, 3, n);
+            PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
+            const double* m = sc.materials + 10 * (size_t)mat;
+            PtVec3 color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * pt_v3(m[0], m[1], m[2]);  // material.rs:148
+            fr.store3(L.depth, 0, L.ray.d);
+            fr.store3(L.depth, 3, P);
+            fr.store3(L.depth, 6, N);
+            fr.store3(L.depth, 9, color);
+            fr.store_tag(L.depth, mat, 0);
+            L.light = 0;
+            L.stage = PT_ST_LIGHT;
+            continue;
+        }
+        case PT_ST_LIGHT: {  // material.rs:149-179
+            if (L.light >= sc.n_lights) { L.stage = PT_ST_AFTER_LIGHTS; continue; }
+            const double* light = sc.lights + 15 * (size_t)L.light;
+            bool is_area;
+            PtVec3 lpos = pt_light_position(a, L, light, L.draw, &is_area);
+            if (is_area) L.draw += 2;
+            PtVec3 P = fr.load3(L.depth, 3);
+            PtVec3 hit_to_light = lpos - P;
+            double light_dist = pt_length(hit_to_light);
+            L.ray.o = P;
+            L.ray.d = hit_to_light / light_dist;
+            L.ray_any = true; L.has_ray = true; L.stage = PT_ST_SHADOW_DONE;
+            if (STATS) cnt->shadow++;
+            return;
+        }
+        case PT_ST_SHADOW_DONE: {  // material.rs:179-210
+            if (hit.node == PT_NO_HIT) {
+                const double* light = sc.lights + 15 * (size_t)L.light;
+                bool is_area;
+                PtVec3 lpos = pt_light_position(a, L, light, L.draw - 2, &is_area);
+                PtVec3 lcol = pt_v3(light[3], light[4], light[5]);
+                PtVec3 ray_dir = fr.load3(L.depth, 0), P = fr.load3(L.depth, 3), N = fr.load3(L.depth, 6), color = fr.load3(L.depth, 9);
+                uint32_t mat, fstage;
+                fr.load_tag(L.depth, &mat, &fstage);
+                const double* m = sc.materials + 10 * (size_t)mat;
+                PtVec3 kd = pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
+                PtVec3 hit_to_light = lpos - P;
+                double light_dist = pt_length(hit_to_light);
+                PtVec3 light_dir = hit_to_light / light_dist;
+                double attenuation = light[6] + light[7] * light_dist + light[8] * light_dist * light_dist;  // light.rs:31-33
+                double normal_light = fmax(pt_dot(N, light_dir), 0.0);
+                PtVec3 diffuse = (kd * lcol) * normal_light;
+                PtVec3 specular = pt_v3(0.0, 0.0, 0.0);
+                if (ks.x > PT_EPSILON || ks.y > PT_EPSILON || ks.z > PT_EPSILON) {
+                    PtVec3 view = -ray_dir;
+                    PtVec3 half = pt_normalized(view + light_dir);
+                    double nhs = pow(fmax(pt_dot(N, half), 0.0), 4.0 * m[6]);
+                    specular = (ks * lcol) * nhs;
+                }
+                color = color + (diffuse + specular) / attenuation;
+                fr.store3(L.depth, 9, color);
+            }
+            L.light++;
+            L.stage = PT_ST_LIGHT;
+            continue;
+        }
+        default: {  // PT_ST_AFTER_LIGHTS: material.rs:216-243
+            uint32_t mat, fstage;
+            fr.load_tag(L.depth, &mat, &fstage);
+            const double* m = sc.materials + 10 * (size_t)mat;
+            double reflectivity = m[7], glossy = m[8];
+            PtVec3 color = fr.load3(L.depth, 9);
+            if (!(reflectivity > 0.0)) { value = color; returning = true; continue; }
+            PtVec3 ray_dir = fr.load3(L.depth, 0), N = fr.load3(L.depth, 6);
+            PtVec3 reflect_dir = ray_dir - (N * 2.0) * pt_dot(ray_dir, N);  // material.rs:218
+            if (glossy > 0.0) {  // material.rs:221-239 (not renormalised: quirk Q5)
+                PtVec3 off = (fabs(reflect_dir.x) < PT_EPSILON && fabs(reflect_dir.y) < PT_EPSILON)
+                                 ? reflect_dir + pt_v3(0.0, 0.1, 0.0) : reflect_dir + pt_v3(0.0, 0.0, 0.1);
+                PtVec3 u_basis = pt_cross(reflect_dir, off);
+                PtVec3 v_basis = pt_cross(reflect_dir, u_basis);
+                uint64_t pixel = (uint64_t)L.y * a.width + L.x;
+                double u_coord = -glossy / 2.0 + pt_rng_f64(a.seed, pixel, L.sample, L.draw) * glossy;
+                double v_coord = -glossy / 2.0 + pt_rng_f64(a.seed, pixel, L.sample, L.draw + 1) * glossy;
+                L.draw += 2;
+                reflect_dir = reflect_dir + (u_basis * u_coord + v_basis * v_coord);
+            }
+            fr.store_tag(L.depth, mat, PT_FS_WAIT_REFLECT);
+            if (L.depth + 1 > PT_MAX_DEPTH) {  // depth-11 ray: its colour is always the background
+                if (STATS) cnt->depth11_skipped++;
+                L.depth++;
+                value = pt_background(a, L.x, L.y);
+                returning = true;
+                continue;
+            }
+            L.ray.o = fr.load3(L.depth, 3);
+            L.ray.d = reflect_dir;
+            L.depth++;
+            L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
+            if (STATS) cnt->reflect++;
+            return;
+        }
+        }
+    }
+}

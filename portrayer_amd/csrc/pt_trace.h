@@ -1,0 +1,223 @@
+// Nearest-hit / any-hit traversal: replaces `scene.root.ray_cast(ray, &mut t_range)`.
+//
+// FLAT mode reproduces the reference's flat_scene semantics (ray.rs:87-99 fold over
+// Vec<FlatSceneNode>, flat_scene.rs:71-99): every candidate is tested in ITS OWN model space over
+// [EPSILON, t_best) and the nearest wins, the lowest flat index winning exact ties. That result
+// does not depend on the order candidates are visited in, so the kernels walk a bounding-volume
+// tree built by pt_scene_upload instead of scanning all nodes, and break exact ties by index.
+//
+// KD mode reproduces the reference's `kdtree` feature bit for bit (kdtree/node.rs:66-203): the
+// reference's own tree (built on the host like kdtree/leaf.rs:89-231), front-to-back with the
+// range clipped at every straddled plane, because Cone/Cylinder results depend on the clipped
+// range start (quirk Q1, cone.rs:64-76).
+//
+// The traversal stack lives in LDS: one column of 32-bit words per lane (word i of lane l at
+// base[i * stride + l]) so that a wave's pushes and pops hit 64 different banks.
+#pragma once
+
+#include "pt_prims.h"
+#include "pt_scene_view.h"
+
+#define PT_NO_HIT 0xFFFFFFFFu
+
+struct PtHit {
+    double t;       // ray parameter of the best hit so far; doubles as the exclusive range end
+    uint32_t node;  // flat node index, PT_NO_HIT when nothing was hit
+    uint32_t sub;   // analytic: part tag; mesh / triangle: global triangle index
+};
+
+struct PtStack {
+    uint32_t* base;
+    int stride;
+    int cap;
+};
+
+PT_HD void pt_push(const PtStack& s, int& sp, uint32_t v) { s.base[sp * s.stride] = v; sp++; }
+PT_HD uint32_t pt_pop(const PtStack& s, int& sp) { sp--; return s.base[sp * s.stride]; }
+PT_HD void pt_push_f64(const PtStack& s, int& sp, double v) {
+    union { double d; uint32_t u[2]; } c; c.d = v;
+    pt_push(s, sp, c.u[0]); pt_push(s, sp, c.u[1]);
+}
+PT_HD double pt_pop_f64(const PtStack& s, int& sp) {
+    union { double d; uint32_t u[2]; } c;
+    c.u[1] = pt_pop(s, sp); c.u[0] = pt_pop(s, sp);
+    return c.d;
+}
+
+// Slab test of one child box against [0, tmax]. NaNs from 0 * inf drop out of fmin/fmax
+// (minNum semantics); boxes are padded at build time so rounding here cannot lose a hit.
+PT_HD bool pt_slab(const double* lo, const double* hi, PtVec3 o, PtVec3 inv, double tmax, double* tnear) {
+    double x0 = (lo[0] - o.x) * inv.x, x1 = (hi[0] - o.x) * inv.x;
+    double y0 = (lo[1] - o.y) * inv.y, y1 = (hi[1] - o.y) * inv.y;
+    double z0 = (lo[2] - o.z) * inv.z, z1 = (hi[2] - o.z) * inv.z;
+    double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), 0.0));
+    double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), tmax));
+    *tnear = tn;
+    return tn <= tf * 1.0000000000000004;
+}
+
+// Generic walk of the build's two-child tree. leaf(first, count, sp) tests the items and returns
+// true to stop the walk (any-hit). `tmax` is re-read after every leaf so shrinking it culls.
+template <bool STATS, class Leaf>
+PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, int32_t root, int32_t root_count, const PtRay& r, const double& tmax,
+                       const PtStack& stk, int sp0, Leaf&& leaf, PtCounters* cnt) {
+    int sp = sp0;
+    PtVec3 inv = pt_v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    int32_t cur = root, cur_count = root_count;
+    for (;;) {
+        if (cur >= 0) {
+            const PtBvhNode& n = nodes[cur];
+            if (STATS) cnt->n_inner++;
+            double t0, t1;
+            bool h0 = pt_slab(n.lo0, n.hi0, r.o, inv, tmax, &t0);
+            bool h1 = pt_slab(n.lo1, n.hi1, r.o, inv, tmax, &t1);
+            int32_t c0 = n.child0, c1 = n.child1, k0 = n.count0, k1 = n.count1;
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                int32_t nc = swap ? c1 : c0, nk = swap ? k1 : k0, fc = swap ? c0 : c1, fk = swap ? k0 : k1;
+                if (sp + 2 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
+                pt_push(stk, sp, (uint32_t)fc); pt_push(stk, sp, (uint32_t)fk);
+                cur = nc; cur_count = nk;
+                continue;
+            } else if (h0) { cur = c0; cur_count = k0; continue; }
+            else if (h1) { cur = c1; cur_count = k1; continue; }
+        } else {
+            if (STATS) cnt->n_leaf++;
+            if (leaf((uint32_t)~cur, (uint32_t)cur_count, sp)) return true;
+        }
+        if (sp == sp0) return false;
+        cur_count = (int32_t)pt_pop(stk, sp);
+        cur = (int32_t)pt_pop(stk, sp);
+    }
+}
+
+// Exclusive range end for a candidate: t == best.t is admitted only when the candidate comes
+// before the current winner in flat order (ray.rs:87-99: the first of equal hits wins).
+PT_HD double pt_cand_end(const PtHit& best, uint32_t node, uint32_t sub) {
+    bool before = best.node != PT_NO_HIT && (node < best.node || (node == best.node && sub < best.sub));
+    return before ? pt_next_up(best.t) : best.t;
+}
+
+// flat_scene.rs:71-99 for one flattened node: transform the ray into model space, dispatch on the
+// primitive (primitive.rs:55-62), keep the hit if it beats `best`. Returns true if best changed.
+template <bool STATS>
+PT_HD bool pt_test_node(const PtSceneView& sc, uint32_t node, const PtRay& ray, double start, PtHit& best, bool any,
+                        const PtStack& stk, int sp, PtCounters* cnt) {
+    const uint32_t* info = sc.info + 4 * (size_t)node;
+    uint32_t type = info[0], data = info[1];
+    PtRay local = pt_ray_to_local(sc.inv + 12 * (size_t)node, ray);
+    if (STATS) cnt->n_analytic++;
+    double t;
+    uint32_t part = 0;
+    bool hit;
+    switch (type) {
+    case PT_SPHERE: hit = pt_sphere_hit(local, start, pt_cand_end(best, node, 0), &t); break;
+    case PT_PLANE: hit = pt_plane_hit(local, start, pt_cand_end(best, node, 0), &t); break;
+    case PT_CUBE: hit = pt_cube_hit(local, start, pt_cand_end(best, node, 0), &t, &part); break;
+    case PT_CYLINDER: hit = pt_cylinder_hit(local, start, pt_cand_end(best, node, 0), &t, &part); break;
+    case PT_CONE: hit = pt_cone_hit(local, start, pt_cand_end(best, node, 0), &t, &part); break;
+    case PT_TRIANGLE: {  // stand-alone triangle, stored after the mesh triangles
+        double beta, gamma;
+        if (STATS) cnt->n_tri++;
+        hit = pt_triangle_hit(sc.tri_v + 9 * (size_t)data, local, start, pt_cand_end(best, node, data), &t, &beta, &gamma);
+        part = data;
+        break;
+    }
+    default: {  // PT_MESH / PT_KDMESH: mesh.rs:146-167 (box test, then the nearest triangle)
+        const PtMeshInfo& m = sc.meshes[data];
+        if (STATS) cnt->n_bbox++;
+        if (!pt_bbox_test_hit(m.bbox_inv, local, start, pt_cand_end(best, node, 0))) return false;
+        bool changed = false;
+        const double* tri_v = sc.tri_v;
+        pt_bvh_walk<STATS>(sc.bvh, m.blas_root, m.blas_root_count, local, best.t, stk, sp,
+            [&](uint32_t first, uint32_t count, int) -> bool {
+                for (uint32_t i = 0; i < count; i++) {
+                    uint32_t tri = sc.bvh_items[first + i];
+                    double tt, beta, gamma;
+                    if (STATS) cnt->n_tri++;
+                    if (pt_triangle_hit(tri_v + 9 * (size_t)tri, local, start, pt_cand_end(best, node, tri), &tt, &beta, &gamma)) {
+                        best.t = tt; best.node = node; best.sub = tri;
+                        changed = true;
+                        if (any) return true;
+                    }
+                }
+                return false;
+            }, cnt);
+        return changed;
+    }
+    }
+    if (!hit) return false;
+    best.t = t; best.node = node; best.sub = part;
+    return true;
+}
+
+// FLAT mode: nearest hit over [EPSILON, inf) (ray.rs:139-141), or any hit for shadow rays
+// (material.rs:174-179 only asks is_none()).
+// `any` is a per-lane run-time flag, not a template parameter: lanes carrying shadow rays and lanes
+// carrying primary / secondary rays walk the tree together in one instruction stream.
+template <bool STATS>
+PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
+    best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
+    if (sc.n_nodes == 0) return false;
+    pt_bvh_walk<STATS>(sc.bvh, sc.tlas_root, sc.tlas_root_count, ray, best.t, stk, 0,
+        [&](uint32_t first, uint32_t count, int sp) -> bool {
+            for (uint32_t i = 0; i < count; i++) {
+                uint32_t node = sc.bvh_items[first + i];
+                if (pt_test_node<STATS>(sc, node, ray, PT_EPSILON, best, any, stk, sp, cnt) && any) return true;
+            }
+            return false;
+        }, cnt);
+    return best.node != PT_NO_HIT;
+}
+
+PT_HD double pt_axis(PtVec3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+// KD mode: kdtree/node.rs:112-202. Pending far sides are kept as (node, start, end) = 5 words.
+template <bool STATS>
+PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
+    best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
+    double start = PT_EPSILON, end = INFINITY;  // ray.rs:140
+    int sp = 0;
+    int32_t cur = 0;
+    const double extent = sc.kd_extent;
+    for (;;) {
+        const PtKdNode n = sc.kd[cur];
+        if (n.axis < 0) {  // Leaf: ray.rs:87-99 fold over the leaf's nodes, reference order, strict ends
+            if (STATS) cnt->n_leaf++;
+            bool found = false;
+            for (int32_t i = 0; i < n.count; i++) {
+                PtHit lb; lb.t = end; lb.node = PT_NO_HIT; lb.sub = 0;
+                if (pt_test_node<STATS>(sc, sc.kd_items[n.first + i], ray, start, lb, any, stk, sp, cnt)) {
+                    best = lb; end = lb.t; found = true;
+                    if (any) return true;
+                }
+            }
+            if (found) return true;  // node.rs:153-157: the first side that hits wins
+        } else {
+            if (STATS) cnt->n_inner++;
+            double t_max = start + extent;                                   // node.rs:118
+            if (!pt_in_range(start, end, t_max)) t_max = end - PT_EPSILON;   // node.rs:121
+            double t_min = start + PT_EPSILON;                               // node.rs:124
+            double o = pt_axis(ray.o, n.axis), d = pt_axis(ray.d, n.axis);
+            bool s = ((o + d * t_min) - n.plane) >= 0.0;                     // infinite_plane.rs:27-35
+            bool e = ((o + d * t_max) - n.plane) >= 0.0;
+            if (s == e) { cur = s ? n.front : n.back; continue; }
+            double plane_t = (n.plane - o) / d;                              // node.rs:90-109
+            if (pt_in_range(start, end, plane_t)) {
+                if (sp + 5 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
+                pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));
+                pt_push_f64(stk, sp, plane_t);
+                pt_push_f64(stk, sp, end);
+                cur = s ? n.front : n.back;
+                end = plane_t;
+                continue;
+            }
+            // node.rs:146-147 / :177-178: the reference panics here; report a miss for this subtree
+            if (STATS) cnt->kd_plane_miss++;
+        }
+        if (sp == 0) return false;
+        end = pt_pop_f64(stk, sp);
+        start = pt_pop_f64(stk, sp);
+        cur = (int32_t)pt_pop(stk, sp);
+    }
+}
