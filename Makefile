@@ -6,7 +6,22 @@ HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-f
 CSRC := portrayer_amd/csrc
 HIP_HDRS := $(wildcard $(CSRC)/*.h) include/portrayer_hip.h
 
-all: portrayer_amd/libportrayer_hip.so
+CXX ?= g++
+CXXFLAGS ?= -O2 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Wno-unused-parameter -Wno-missing-field-initializers
+HOST := portrayer_amd/host
+HOST_SRCS := $(HOST)/portrayer.cpp $(HOST)/capi.cpp $(wildcard examples/*.cpp)
+HOST_HDRS := $(wildcard $(HOST)/*.hpp) examples/examples.hpp include/portrayer_host.h include/portrayer_hip.h
+EXAMPLES := single-triangle primitives-simple macho-cows entering-the-mirror-dimension big-scene
+
+all: portrayer_amd/libportrayer_hip.so portrayer_amd/libportrayer_host.so $(addprefix examples/bin/,$(EXAMPLES))
+
+# C++ host layer (scene API, flatten, k-d build, camera, Image) + the transliterated example scenes
+portrayer_amd/libportrayer_host.so: $(HOST_SRCS) $(HOST_HDRS) portrayer_amd/libportrayer_hip.so
+	$(CXX) $(CXXFLAGS) -shared $(HOST_SRCS) -o $@ -Lportrayer_amd -lportrayer_hip -lz -Wl,-rpath,'$$ORIGIN'
+
+examples/bin/%: examples/%.cpp portrayer_amd/libportrayer_host.so
+	@mkdir -p examples/bin
+	$(CXX) $(CXXFLAGS) -fPIE -DPORTRAYER_EXAMPLE_MAIN $< -o $@ -Lportrayer_amd -lportrayer_host -lportrayer_hip -Wl,-rpath,'$$ORIGIN/../../portrayer_amd'
 
 portrayer_amd/libportrayer_hip.so: $(CSRC)/pt_api.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/pt_api.hip -o $@
@@ -16,5 +31,6 @@ oracle:
 
 clean:
 	rm -f portrayer_amd/*.so
+	rm -rf examples/bin
 	$(MAKE) -C oracle clean
 .PHONY: all oracle clean

@@ -1,0 +1,32 @@
+// The reference's scene scripts (examples/*.rs) transliterated against portrayer.hpp. Each
+// function builds the scene exactly as the script's main() does; `main()` itself (render + save)
+// is compiled when PORTRAYER_EXAMPLE_MAIN is defined.
+#pragma once
+
+#include <string>
+
+#include "../portrayer_amd/host/portrayer.hpp"
+
+namespace portrayer {
+namespace examples {
+
+struct Example {
+    scene::HierScene scene;
+    camera::CameraSettings cam;
+    size_t width, height;
+    std::string output;
+};
+
+// |uv| Rgb {r: 0.2, g: 0.4, b: 0.6} * (1.0 - uv.v) + Rgb::blue() * uv.v — the closure every script passes
+inline math::Rgb sky(math::Uv uv) { return math::Rgb{0.2, 0.4, 0.6} * (1.0 - uv.v) + math::Rgb::blue() * uv.v; }
+
+Example single_triangle();                                       // examples/single-triangle.rs
+Example primitives_simple();                                     // examples/primitives-simple.rs
+Example macho_cows(const std::string& assets_dir);               // examples/macho-cows.rs
+Example entering_the_mirror_dimension(const std::string& assets_dir);  // examples/entering-the-mirror-dimension.rs
+Example big_scene(int n = 10);                                   // examples/big-scene.rs (n = objects per axis)
+
+int run_main(Example ex);  // Image::new(..)? ; image.render::<RenderProgress, _>(..) ; image.save()
+
+}  // namespace examples
+}  // namespace portrayer

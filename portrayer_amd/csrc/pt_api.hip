@@ -330,7 +330,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         for (int r = 0; r < 12; r++) mi.bbox_inv[r] = s->mesh_bounds_invtrans ? s->mesh_bounds_invtrans[16 * (size_t)m + r] : 0.0;
         if (!s->mesh_bounds_invtrans) return pt_fail(c, PT_ERR_ARGUMENT, "mesh_bounds_invtrans missing");
         mi.tri_first = (uint32_t)t0; mi.tri_count = (uint32_t)(t1 - t0);
-        mi.blas_root = ref.child; mi.blas_root_count = ref.count;
+        mi.blas_root = ref.child; mi.pad = 0;
         for (int k = 0; k < 3; k++) { mb.lo[k] -= 1e-5 * ext; mb.hi[k] += 1e-5 * ext; }
         mesh_box[m] = mb;
     }
@@ -424,11 +424,11 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.meshes = (const PtMeshInfo*)c->meshes.p; v.materials = (const double*)c->materials.p; v.lights = (const double*)c->lights.p;
     for (int k = 0; k < 3; k++) v.ambient[k] = s->ambient[k];
     v.bvh = (const PtBvhNode*)c->bvh.p; v.bvh_items = (const uint32_t*)c->bvh_items.p;
-    v.tlas_root = tlas.child; v.tlas_root_count = tlas.count;
+    v.tlas_root = tlas.child; v.pad0 = 0;
     v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
     v.kd_extent = kd_extent;
     v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : PT_MODE_FLAT;
-    int cap = traverse == PT_TRAVERSE_KD ? 5 * (kd_depth + 1) + 2 * max_blas_depth + 4 : 2 * (tlas.depth + max_blas_depth) + 4;
+    int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + max_blas_depth + 2 : tlas.depth + max_blas_depth + 2;
     v.stack_cap = std::max(cap, 8);
     if ((size_t)v.stack_cap * PT_BLOCK * 4 > 64 * 1024) return pt_fail(c, PT_ERR_SCENE, "traversal stack would not fit in LDS (tree too deep)");
     c->have_scene = true;

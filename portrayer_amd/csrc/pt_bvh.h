@@ -19,8 +19,7 @@ struct PtBuildBox {
 };
 
 struct PtBvhRef {
-    int32_t child;  // >= 0 inner node, < 0 leaf (~first)
-    int32_t count;
+    uint32_t child;  // packed reference (pt_scene_view.h)
     PtBuildBox box;
     int depth;      // levels below and including this reference
 };
@@ -51,8 +50,7 @@ struct Builder {
 
     PtBvhRef leaf(size_t b, size_t e, const PtBuildBox& box) {
         PtBvhRef r;
-        r.child = ~(int32_t)items->size();
-        r.count = (int32_t)(e - b);
+        r.child = PT_REF_LEAF | ((uint32_t)items->size() << 3) | (uint32_t)(e - b - 1);
         for (size_t i = b; i < e; i++) items->push_back(ids ? ids[order[i]] : order[i]);
         r.box = box;
         r.depth = 1;
@@ -70,7 +68,7 @@ struct Builder {
             }
         }
         size_t n = e - b;
-        if (n <= (size_t)max_leaf || level >= 56) return leaf(b, e, box);
+        if (n <= (size_t)max_leaf) return leaf(b, e, box);
         // binned SAH over the three axes
         const int NB = 16;
         double best_cost = INFINITY; int best_axis = -1, best_bin = -1;
@@ -98,8 +96,8 @@ struct Builder {
             }
         }
         size_t mid;
-        if (best_axis < 0) {
-            mid = b + n / 2;  // all centroids coincide: split by position in the list
+        if (best_axis < 0 || level > 32) {
+            mid = b + n / 2;  // all centroids coincide (or a degenerate, very deep tree): split by position in the list
         } else {
             double c0 = cbox.lo[best_axis], scale = NB / (cbox.hi[best_axis] - c0);
             auto it = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t i) {
@@ -117,9 +115,9 @@ struct Builder {
         PtBvhRef r = build(mid, e, level + 1);
         PtBvhNode& nd = (*nodes)[idx];
         for (int k = 0; k < 3; k++) { nd.lo0[k] = l.box.lo[k]; nd.hi0[k] = l.box.hi[k]; nd.lo1[k] = r.box.lo[k]; nd.hi1[k] = r.box.hi[k]; }
-        nd.child0 = l.child; nd.count0 = l.count; nd.child1 = r.child; nd.count1 = r.count;
+        nd.child0 = l.child; nd.child1 = r.child;
         PtBvhRef out;
-        out.child = idx; out.count = 0; out.box = box; out.depth = 1 + std::max(l.depth, r.depth);
+        out.child = (uint32_t)idx; out.box = box; out.depth = 1 + std::max(l.depth, r.depth);
         return out;
     }
 };
@@ -131,11 +129,11 @@ struct Builder {
 inline PtBvhRef pt_bvh_build(const PtBuildBox* boxes, const uint32_t* ids, size_t n, int max_leaf,
                              std::vector<PtBvhNode>& nodes, std::vector<uint32_t>& items) {
     pt_bvh_detail::Builder b;
-    b.boxes = boxes; b.ids = ids; b.max_leaf = max_leaf; b.nodes = &nodes; b.items = &items;
+    b.boxes = boxes; b.ids = ids; b.max_leaf = std::max(1, std::min(max_leaf, 8)); b.nodes = &nodes; b.items = &items;
     b.order.resize(n);
     for (size_t i = 0; i < n; i++) b.order[i] = (uint32_t)i;
     if (n == 0) {
-        PtBvhRef r; r.child = ~(int32_t)items.size(); r.count = 0; r.box = pt_bvh_detail::empty_box(); r.depth = 1;
+        PtBvhRef r; r.child = PT_REF_EMPTY; r.box = pt_bvh_detail::empty_box(); r.depth = 1;
         return r;
     }
     return b.build(0, n, 0);

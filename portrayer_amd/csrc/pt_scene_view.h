@@ -18,13 +18,15 @@
 
 enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2 };
 
-// Two children per record so one fetch decides both sides. child >= 0: inner node index;
-// child < 0: leaf, items[first .. first+count) with first = ~child.
+// Two children per record so one fetch decides both sides. A child reference is one 32-bit word
+// (one traversal-stack slot): bit 31 clear = inner node index; bit 31 set = leaf with
+// items[first .. first + count), first in bits 30..3, count - 1 in bits 2..0 (1 <= count <= 8).
+#define PT_REF_LEAF 0x80000000u
+#define PT_REF_EMPTY 0xFFFFFFFFu
 struct PtBvhNode {
     double lo0[3], hi0[3], lo1[3], hi1[3];
-    int32_t child0, child1;
-    int32_t count0, count1;
-};  // 112 bytes
+    uint32_t child0, child1;
+};  // 104 bytes
 
 struct PtKdNode {
     double plane;          // coordinate of the separating plane on `axis`
@@ -37,8 +39,8 @@ struct PtKdNode {
 struct PtMeshInfo {
     double bbox_inv[12];   // rows 0..2 of BoundingBox::invtrans (bounding_box.rs:55-82)
     uint32_t tri_first, tri_count;
-    int32_t blas_root;     // encoded like PtBvhNode::child (may be a leaf)
-    int32_t blas_root_count;
+    uint32_t blas_root;    // encoded like PtBvhNode::child0 (may be a leaf, or PT_REF_EMPTY)
+    uint32_t pad;
 };
 
 struct PtSceneView {
@@ -55,7 +57,7 @@ struct PtSceneView {
     double ambient[3];
     const PtBvhNode* bvh;
     const uint32_t* bvh_items;
-    int32_t tlas_root, tlas_root_count;
+    uint32_t tlas_root, pad0;
     const PtKdNode* kd;
     const uint32_t* kd_items;
     double kd_extent;  // bounding_box.rs:95-99: squared diagonal of the root bounds

@@ -59,35 +59,34 @@ PT_HD bool pt_slab(const double* lo, const double* hi, PtVec3 o, PtVec3 inv, dou
 // Generic walk of the build's two-child tree. leaf(first, count, sp) tests the items and returns
 // true to stop the walk (any-hit). `tmax` is re-read after every leaf so shrinking it culls.
 template <bool STATS, class Leaf>
-PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, int32_t root, int32_t root_count, const PtRay& r, const double& tmax,
+PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, const double& tmax,
                        const PtStack& stk, int sp0, Leaf&& leaf, PtCounters* cnt) {
+    if (root == PT_REF_EMPTY) return false;
     int sp = sp0;
     PtVec3 inv = pt_v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
-    int32_t cur = root, cur_count = root_count;
+    uint32_t cur = root;
     for (;;) {
-        if (cur >= 0) {
+        if (!(cur & PT_REF_LEAF)) {
             const PtBvhNode& n = nodes[cur];
             if (STATS) cnt->n_inner++;
             double t0, t1;
             bool h0 = pt_slab(n.lo0, n.hi0, r.o, inv, tmax, &t0);
             bool h1 = pt_slab(n.lo1, n.hi1, r.o, inv, tmax, &t1);
-            int32_t c0 = n.child0, c1 = n.child1, k0 = n.count0, k1 = n.count1;
+            uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
-                int32_t nc = swap ? c1 : c0, nk = swap ? k1 : k0, fc = swap ? c0 : c1, fk = swap ? k0 : k1;
-                if (sp + 2 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
-                pt_push(stk, sp, (uint32_t)fc); pt_push(stk, sp, (uint32_t)fk);
-                cur = nc; cur_count = nk;
+                if (sp + 1 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
+                pt_push(stk, sp, swap ? c0 : c1);
+                cur = swap ? c1 : c0;
                 continue;
-            } else if (h0) { cur = c0; cur_count = k0; continue; }
-            else if (h1) { cur = c1; cur_count = k1; continue; }
+            } else if (h0) { cur = c0; continue; }
+            else if (h1) { cur = c1; continue; }
         } else {
             if (STATS) cnt->n_leaf++;
-            if (leaf((uint32_t)~cur, (uint32_t)cur_count, sp)) return true;
+            if (leaf((cur & ~PT_REF_LEAF) >> 3, (cur & 7u) + 1u, sp)) return true;
         }
         if (sp == sp0) return false;
-        cur_count = (int32_t)pt_pop(stk, sp);
-        cur = (int32_t)pt_pop(stk, sp);
+        cur = pt_pop(stk, sp);
     }
 }
 
@@ -129,7 +128,7 @@ PT_HD bool pt_test_node(const PtSceneView& sc, uint32_t node, const PtRay& ray, 
         if (!pt_bbox_test_hit(m.bbox_inv, local, start, pt_cand_end(best, node, 0))) return false;
         bool changed = false;
         const double* tri_v = sc.tri_v;
-        pt_bvh_walk<STATS>(sc.bvh, m.blas_root, m.blas_root_count, local, best.t, stk, sp,
+        pt_bvh_walk<STATS>(sc.bvh, m.blas_root, local, best.t, stk, sp,
             [&](uint32_t first, uint32_t count, int) -> bool {
                 for (uint32_t i = 0; i < count; i++) {
                     uint32_t tri = sc.bvh_items[first + i];
@@ -159,7 +158,7 @@ template <bool STATS>
 PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
     best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
     if (sc.n_nodes == 0) return false;
-    pt_bvh_walk<STATS>(sc.bvh, sc.tlas_root, sc.tlas_root_count, ray, best.t, stk, 0,
+    pt_bvh_walk<STATS>(sc.bvh, sc.tlas_root, ray, best.t, stk, 0,
         [&](uint32_t first, uint32_t count, int sp) -> bool {
             for (uint32_t i = 0; i < count; i++) {
                 uint32_t node = sc.bvh_items[first + i];
@@ -172,7 +171,9 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
 
 PT_HD double pt_axis(PtVec3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
-// KD mode: kdtree/node.rs:112-202. Pending far sides are kept as (node, start, end) = 5 words.
+// KD mode: kdtree/node.rs:112-202. A pending far side is (node, start) = 3 words: its range end is
+// the start of the entry below it on the stack (or +inf), because the current `end` always equals
+// the plane parameter of the innermost straddled split whose near side is being walked.
 template <bool STATS>
 PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
     best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
@@ -204,10 +205,9 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
             if (s == e) { cur = s ? n.front : n.back; continue; }
             double plane_t = (n.plane - o) / d;                              // node.rs:90-109
             if (pt_in_range(start, end, plane_t)) {
-                if (sp + 5 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 3 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
                 pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));
                 pt_push_f64(stk, sp, plane_t);
-                pt_push_f64(stk, sp, end);
                 cur = s ? n.front : n.back;
                 end = plane_t;
                 continue;
@@ -216,8 +216,9 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
             if (STATS) cnt->kd_plane_miss++;
         }
         if (sp == 0) return false;
-        end = pt_pop_f64(stk, sp);
         start = pt_pop_f64(stk, sp);
         cur = (int32_t)pt_pop(stk, sp);
+        if (sp == 0) end = INFINITY;
+        else { int peek = sp; end = pt_pop_f64(stk, peek); }
     }
 }

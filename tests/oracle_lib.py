@@ -140,7 +140,9 @@ class PackedScene:
         return C.byref(self.struct)
 
 
-def pack(scene: Scene) -> PackedScene:
+def arrays_from_dsl(scene: Scene):
+    """Linearises a DSL scene into the po_scene arrays; node matrices come from the oracle's own
+    builder-call composition (po_mat4_compose)."""
     lin = linearise(scene)
     n = len(lin.nodes)
     a = {}
@@ -168,25 +170,37 @@ def pack(scene: Scene) -> PackedScene:
     a["tri_has_normals"] = np.array([1 if t.tri_normals is not None else 0 for t in lin.triangles] + [0], dtype=np.uint8)
     a["materials"] = np.array([m.row() for m in lin.materials] or [[0.0] * 10], dtype=np.float64)
     a["lights"] = np.array([l.row() for l in scene.lights] or [[0.0] * 15], dtype=np.float64)
-    for k in a:
-        a[k] = np.ascontiguousarray(a[k])
+    a["ambient"] = np.array(list(map(float, scene.ambient)))
+    a.update(root=lin.root, n_meshes=len(lin.meshes), n_triangles=nt, n_materials=len(lin.materials), n_lights=len(scene.lights))
+    return a, lin
+
+
+def pack_arrays(a: dict, lin=None) -> PackedScene:
+    """po_scene over a dict of arrays (from arrays_from_dsl, or exported by the product's host
+    library: portrayer_amd.host.Scene.export())."""
+    a = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in a.items()}
     s = PoScene()
-    s.n_nodes = n
+    s.n_nodes = len(a["prim_type"])
     s.node_trans = _p(a["node_trans"], _dp); s.node_prim_type = _p(a["prim_type"], _ip)
     s.node_prim_data = _p(a["prim_data"], _ip); s.node_prim_flags = _p(a["prim_flags"], _ip)
     s.node_material = _p(a["material"], _ip); s.node_child_off = _p(a["child_off"], _up)
-    s.children = _p(a["children"], _up); s.root = lin.root
-    s.n_meshes = len(lin.meshes)
+    s.children = _p(a["children"], _up); s.root = int(a["root"])
+    s.n_meshes = int(a["n_meshes"])
     s.mesh_vert_off = _p(a["mesh_vert_off"], _u64p); s.mesh_tri_off = _p(a["mesh_tri_off"], _u64p)
     s.mesh_positions = _p(a["mesh_positions"], _dp); s.mesh_normals = _p(a["mesh_normals"], _dp)
     s.mesh_has_normals = _p(a["mesh_has_normals"], _u8p); s.mesh_indices = _p(a["mesh_indices"], _up)
-    s.n_triangles = nt
+    s.n_triangles = int(a["n_triangles"])
     s.tri_vertices = _p(a["tri_vertices"], _dp); s.tri_normals = _p(a["tri_normals"], _dp)
     s.tri_has_normals = _p(a["tri_has_normals"], _u8p)
-    s.n_materials = len(lin.materials); s.materials = _p(a["materials"], _dp)
-    s.n_lights = len(scene.lights); s.lights = _p(a["lights"], _dp)
-    s.ambient = (C.c_double * 3)(*map(float, scene.ambient))
+    s.n_materials = int(a["n_materials"]); s.materials = _p(a["materials"], _dp)
+    s.n_lights = int(a["n_lights"]); s.lights = _p(a["lights"], _dp)
+    s.ambient = (C.c_double * 3)(*map(float, a["ambient"]))
     return PackedScene(s, a, lin)
+
+
+def pack(scene: Scene) -> PackedScene:
+    a, lin = arrays_from_dsl(scene)
+    return pack_arrays(a, lin)
 
 
 def camera_struct(cam: Camera) -> PoCamera:

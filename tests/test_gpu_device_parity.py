@@ -68,10 +68,10 @@ def test_render_matches_oracle(ctx, oracle, name, mode):
     print(f"{name}/{mode}: linear bit-equal {100.0 * (d == 0).mean():.4f} %, max {d.max()} ulp; kernel {st['kernel_ms']:.2f} ms")
     assert np.array_equal(rgb, ref.rgb)
     assert d.max() <= 64  # pow differences (<= 1 ulp each) through at most a few adds
-    if mode == "kd":
-        for k in ("n_analytic", "n_tri", "n_bbox"):
-            pass  # mesh internals differ (own triangle tree); scene-tree counters are compared below
-        assert st["n_analytic"] == ref.stats["n_analytic"]
+    if mode == "kd":  # same tree, same order; shadow rays stop at the first hit of a leaf, the oracle finishes the leaf
+        assert st["n_analytic"] <= ref.stats["n_analytic"]
+        if ref.stats["n_tri"] == 0:  # with meshes n_inner also counts the build's own triangle-tree nodes
+            assert st["n_inner"] <= ref.stats["n_split"]
 
 
 @pytest.mark.parametrize("mode", ["flat", "kd"])
