@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X ray-cast/shade path: Mray/s (primary + shadow + secondary rays) at
+1920x1080, SAMPLES=64 (BASELINE.json `metric`).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload big-scene] [--traversal flat|kd]
+
+A "step" is one full frame of the workload, inputs resident in HBM (scene uploaded once, background
+rows on the device) when the timed region starts. With N > 1 (launched by torch.distributed.run, one
+rank per GPU) the frame's 8x8 tiles are dealt round-robin to the ranks, every rank renders its tiles
+into a compact device buffer, and ONE gather (RCCL over xGMI; `--backend gloo` on CPU tensors for
+tests) brings them to rank 0, which scatters them into the row-major image: fixed total work, so
+`scaling` is "strong". Rank 0 prints one JSON line.
+
+The line also carries
+  roofline     : the render kernel's ALGORITHMIC bytes per launch (SURVEY §8d / DESIGN.md formula, from
+                 the kernel's own ray / node / test counters) over its mean launch duration measured
+                 with HIP events on the launch stream, against the 8 TB/s HBM peak;
+  cpu_baseline : the CPU oracle (a C restatement of the reference, kind "port") timed on this box's
+                 host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+WORKLOADS = {
+    # name: (example scene, big-scene n, width, height, samples)
+    "big-scene": ("big-scene", 10, 1920, 1080, 64),
+    "mirror": ("entering-the-mirror-dimension", 0, 1920, 1080, 64),
+    "cows": ("macho-cows", 0, 1280, 720, 16),
+    "primitives": ("primitives-simple", 0, 800, 600, 1),
+    "triangle": ("single-triangle", 0, 256, 256, 1),
+}
+
+
+def algorithmic_bytes(st, n_lights, pixels, traversal):
+    """B_ray = 56 + node bytes + 104 n_analytic + 72 n_tri + 48 n_bbox + H (168 + 80 + 120 L),
+    summed over all rays of one launch, plus 3 B written and 24 B of background read per pixel. A k-d split
+    record is 16 B (plane + two child indices); a node of this build's two-child bounding-volume tree is
+    104 B (two f64 boxes + two child references)."""
+    rays = st["primary"] + st["shadow"] + st["reflect"] + st["refract"]
+    node_bytes = 16 if traversal == "kd" else 104
+    return (56 * rays + node_bytes * st["n_inner"] + 104 * st["n_analytic"] + 72 * st["n_tri"] + 48 * st["n_bbox"]
+            + st["hits"] * (168 + 80 + 120 * n_lights) + 27 * pixels)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="big-scene", choices=sorted(WORKLOADS))
+    ap.add_argument("--traversal", default="flat", choices=["flat", "kd"])
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--samples", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--same-device", action="store_true", help="testing: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare rank 0's assembled image with a single-GPU render")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    dist = torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime and ours share a SONAME; loaded in this order the
+        # process ends up with ONE runtime.
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+
+    import ctypes as C
+
+    import numpy as np
+
+    from portrayer_amd import _hip as H
+    from portrayer_amd import host
+
+    example, n, w, h, s = WORKLOADS[args.workload]
+    w, h, s = args.width or w, args.height or h, args.samples or s
+    device = 0 if args.same_device else local_rank
+    scene = host.Scene.example(example, n=n or 10)
+    traverse = H.TRAVERSE_KD if args.traversal == "kd" else H.TRAVERSE_FLAT
+    renderer = host.Renderer(scene, traverse, kd_depth=10, device=device)  # flatten + build + upload: once, outside the timed region
+    ctx = renderer.context
+    lib = H.lib()
+    cam = host.camera(scene.camera, w, h)
+    n_lights = scene.export()["n_lights"]
+
+    def check(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with {rc}: {lib.pt_last_error(ctx).decode()}")
+
+    v = np.arange(h, dtype=np.float64) / float(h)  # the example scripts' background closure, one colour per row
+    bg = np.ascontiguousarray(np.array([0.2, 0.4, 0.6])[None, :] * (1.0 - v)[:, None] + np.array([0.0, 0.0, 1.0])[None, :] * v[:, None])
+    d_bg = C.c_void_p()
+    check(lib.pt_device_alloc(ctx, bg.nbytes, C.byref(d_bg)), "pt_device_alloc")
+    check(lib.pt_copy_to_device(ctx, d_bg, bg.ctypes.data_as(C.c_void_p), bg.nbytes), "pt_copy_to_device")
+
+    def params(stats):
+        return H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, rank, world, 1 if stats else 0)
+
+    p = params(False)
+    compact_bytes = int(lib.pt_compact_bytes(C.byref(p)))
+    if world > 1:
+        dev = torch.device("cpu") if args.backend == "gloo" else torch.device(f"cuda:{device}")
+        if args.backend == "nccl":
+            torch.cuda.set_device(device)
+        mine_t = torch.empty(compact_bytes, dtype=torch.uint8, device=dev)
+        gathered_t = torch.empty(compact_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None
+        gather_list = list(gathered_t.chunk(world)) if rank == 0 else None  # views: the gather lands rank-major in one buffer
+    d_mine = C.c_void_p()
+    if world > 1 and args.backend == "gloo":
+        check(lib.pt_device_alloc(ctx, compact_bytes, C.byref(d_mine)), "pt_device_alloc")
+    d_full = C.c_void_p(); d_gath = C.c_void_p()
+    if rank == 0:
+        check(lib.pt_device_alloc(ctx, w * h * 3, C.byref(d_full)), "pt_device_alloc")
+        if world > 1 and args.backend == "gloo":
+            check(lib.pt_device_alloc(ctx, compact_bytes * world, C.byref(d_gath)), "pt_device_alloc")
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+
+    def step(stats=False):
+        """One frame: render own tiles -> (gather -> untile on rank 0). Returns this rank's pt_stats."""
+        pp = params(stats)
+        st = H.PtStats()
+        if world == 1:
+            target, compact = d_full, 0
+        elif args.backend == "nccl":
+            target, compact = C.c_void_p(mine_t.data_ptr()), 1  # render straight into the tensor RCCL sends from
+        else:
+            target, compact = d_mine, 1
+        check(lib.pt_render_device(ctx, C.byref(cam), d_bg, C.byref(pp), compact, target, None), "pt_render_device")
+        check(lib.pt_render_finish(ctx, C.byref(st)), "pt_render_finish")  # waits for the kernel (HIP event)
+        if world > 1:
+            if args.backend == "gloo":
+                check(lib.pt_copy_from_device(ctx, C.c_void_p(mine_t.data_ptr()), d_mine, compact_bytes), "pt_copy_from_device")
+            dist.gather(mine_t, gather_list, dst=0)  # the single collective of the frame
+            if rank == 0:
+                if args.backend == "nccl":
+                    torch.cuda.synchronize()
+                    src = C.c_void_p(gathered_t.data_ptr())
+                else:
+                    check(lib.pt_copy_to_device(ctx, d_gath, C.c_void_p(gathered_t.data_ptr()), compact_bytes * world), "pt_copy_to_device")
+                    src = d_gath
+                check(lib.pt_untile_device(ctx, C.byref(pp), src, d_full, None), "pt_untile_device")
+                check(lib.pt_synchronize(ctx), "pt_synchronize")
+        return st.as_dict()
+
+    # counting pass (untimed): ray / node / test counters of this rank's share of one frame
+    counts = step(stats=True)
+    if counts["stack_overflow"]:
+        raise RuntimeError("traversal stack overflow")
+    keys = ["primary", "shadow", "reflect", "refract", "hits", "n_inner", "n_leaf", "n_analytic", "n_tri", "n_bbox"]
+    total = dict(counts)
+    if world > 1:
+        t = torch.tensor([counts[k] for k in keys], dtype=torch.int64, device=mine_t.device)
+        dist.all_reduce(t)
+        for k, x in zip(keys, t.tolist()):
+            total[k] = int(x)
+    rays_frame = total["primary"] + total["shadow"] + total["reflect"] + total["refract"]
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kernel_ms.append(step()["kernel_ms"])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=mine_t.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ok = None
+    if args.check and rank == 0:
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        check(lib.pt_copy_from_device(ctx, img.ctypes.data_as(C.c_void_p), d_full, img.nbytes), "pt_copy_from_device")
+        one = np.zeros((h, w, 3), dtype=np.uint8)
+        renderer.render(scene.camera, w, h, bg, samples=s, seed=0, sample_mode=H.SAMPLE_RNG, into=one, want_linear=False)
+        ok = bool(np.array_equal(img, one))
+
+    if rank == 0:
+        mean_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+        mine_bytes = algorithmic_bytes(counts, n_lights, compact_bytes // 3 if world > 1 else w * h, args.traversal)
+        achieved = mine_bytes / mean_kernel_s / 1e9
+        out = {
+            "metric": "Mray/s (primary+shadow+secondary) at 1920x1080 SAMPLES=64",
+            "value": rays_frame * args.steps / elapsed / 1e6,
+            "unit": "Mray/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{example} ({'1000 analytic primitives, 3 point lights, ' if example == 'big-scene' else ''}"
+                                   f"reference scene script) {w}x{h} SAMPLES={s}",
+                       "width": w, "height": h, "samples": s, "traversal": args.traversal, "sampling": "counter-based jitter, seed 0",
+                       "partition": f"8x8 tiles round-robin over {world} rank(s), one gather" if world > 1 else "single GPU",
+                       "rays_per_frame": rays_frame,
+                       "rays": {k: total[k] for k in ("primary", "shadow", "reflect", "refract")}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": "pt_render_kernel", "kernel_ms": mean_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": mine_bytes,
+                         "per_ray": {"inner_nodes": total["n_inner"] / rays_frame, "primitive_tests": total["n_analytic"] / rays_frame,
+                                     "triangle_tests": total["n_tri"] / rays_frame}},
+        }
+        if ok is not None:
+            out["config"]["assembled_image_equals_single_gpu_render"] = ok
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(example, n, w, h, args.traversal)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(example, n, w, h, traversal):
+    """The oracle (oracle/portrayer_oracle.c, a C restatement of the reference: kind "port") on all
+    host cores, one frame of the same scene and resolution at SAMPLES=1 — 1/64 of the GPU workload's
+    samples, every pixel covered — in the reference's k-d tree mode (its fastest, `--features kdtree`)."""
+    import oracle_lib as O
+    from portrayer_amd import host
+    O.build()
+    sc = host.Scene.example(example, n=n or 10)
+    ps = O.pack_arrays(sc.export())
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    r = O.render(ps, sc.camera, w, h, samples=1, seed=0, jitter=O.JITTER_RNG, mode=O.MODE_KD, threads=cores)
+    dt = time.perf_counter() - t0
+    rays = r.stats["primary"] + r.stats["shadow"] + r.stats["reflect"] + r.stats["refract"]
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": f"one {w}x{h} frame of the same scene at SAMPLES=1 (1/64 of the samples), reference k-d tree mode (KD_DEPTH=10), "
+                      f"{rays} rays in {dt:.2f} s including scene preparation; C restatement of the reference, not its Rust binary"}
+
+
+if __name__ == "__main__":
+    main()

@@ -176,6 +176,7 @@ int pt_device_alloc(pt_context *ctx, uint64_t bytes, void **out);
 int pt_device_free(pt_context *ctx, void *ptr);
 int pt_copy_to_device(pt_context *ctx, void *dst, const void *src, uint64_t bytes);
 int pt_copy_from_device(pt_context *ctx, void *dst, const void *src, uint64_t bytes);
+int pt_synchronize(pt_context *ctx); /* waits for everything queued on the context's device */
 /* Streams `bytes` from src to dst with 16-byte accesses `iters` times and returns the best GB/s
  * (read + write counted), the measured HBM roofline the renderer is compared with. */
 int pt_measure_copy_bandwidth(pt_context *ctx, uint64_t bytes, int iters, double *gbps);

@@ -76,7 +76,7 @@ _lib: Optional[C.CDLL] = None
 
 EXPORTS = ["pt_abi_version", "pt_device_count", "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_scene_upload",
            "pt_render", "pt_render_device", "pt_render_finish", "pt_compact_bytes", "pt_untile_device", "pt_device_alloc",
-           "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
+           "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_synchronize", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
            "pt_test_math"]
 
 
@@ -114,6 +114,8 @@ def lib() -> C.CDLL:
         l.pt_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         l.pt_copy_from_device.restype = C.c_int
         l.pt_copy_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        l.pt_synchronize.restype = C.c_int
+        l.pt_synchronize.argtypes = [C.c_void_p]
         l.pt_measure_copy_bandwidth.restype = C.c_int
         l.pt_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _dp]
         l.pt_test_cast_rays.restype = C.c_int

@@ -646,6 +646,13 @@ extern "C" int pt_copy_from_device(pt_context* c, void* dst, const void* src, ui
     return PT_OK;
 }
 
+extern "C" int pt_synchronize(pt_context* c) {
+    if (!c) return PT_ERR_ARGUMENT;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipDeviceSynchronize());
+    return PT_OK;
+}
+
 extern "C" int pt_measure_copy_bandwidth(pt_context* c, uint64_t bytes, int iters, double* gbps) {
     if (!c || !gbps || bytes < 16) return PT_ERR_ARGUMENT;
     PT_HIP(c, hipSetDevice(c->device));

@@ -203,8 +203,13 @@ def pack(scene: Scene) -> PackedScene:
     return pack_arrays(a, lin)
 
 
-def camera_struct(cam: Camera) -> PoCamera:
+def camera_struct(cam) -> PoCamera:
+    """cam: a scene_dsl.Camera, or 10 doubles (eye, center, up, fovy in radians)."""
     c = PoCamera()
+    if not isinstance(cam, Camera):
+        v = [float(x) for x in cam]
+        c.eye = (C.c_double * 3)(*v[0:3]); c.center = (C.c_double * 3)(*v[3:6]); c.up = (C.c_double * 3)(*v[6:9]); c.fovy_radians = v[9]
+        return c
     c.eye = (C.c_double * 3)(*map(float, cam.eye)); c.center = (C.c_double * 3)(*map(float, cam.center))
     c.up = (C.c_double * 3)(*map(float, cam.up)); c.fovy_radians = cam.fovy_radians
     return c
