@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 # -ffp-contract=off: the reference (Rust/LLVM) never fuses a*b+c; parity depends on it.
-HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-value
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-value $(EXTRA_HIPFLAGS)
 CSRC := portrayer_amd/csrc
 HIP_HDRS := $(wildcard $(CSRC)/*.h) include/portrayer_hip.h
 

@@ -27,6 +27,9 @@
 #include "pt_shade.h"
 
 #define PT_BLOCK 256
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 2  // waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Kernels
@@ -45,7 +48,7 @@ __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCount
 }
 
 template <int MODE, bool STATS>
-__global__ void __launch_bounds__(PT_BLOCK) pt_render_kernel(PtRenderArgs a) {
+__global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRenderArgs a) {
     extern __shared__ uint32_t pt_lds[];
     PtStack stk;
     stk.base = pt_lds + threadIdx.x;
@@ -352,11 +355,30 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         if (t == PT_PRIM_TRIANGLE) data = (uint32_t)(mesh_tris + data);
         info[4 * (size_t)i] = (uint32_t)t; info[4 * (size_t)i + 1] = data;
         info[4 * (size_t)i + 2] = (uint32_t)s->prim_flags[i]; info[4 * (size_t)i + 3] = (uint32_t)s->material[i];
-        // conservative model-space box: every hit the primitive tests can accept lies inside it
-        // (cube.rs:25 / plane.rs:31 accept points up to 1e-5 outside the unit shape)
+        // Conservative world-space box: every hit the primitive tests can accept lies inside it
+        // (cube.rs:25 / plane.rs:31 accept points up to 1e-5 outside the unit shape; all shapes are
+        // padded by 1e-4 model units). Spheres, cylinders and cones get their exact boxes under the
+        // affine transform instead of the box of their transformed unit cube.
+        const double* M = &s->trans[16 * (size_t)i];
+        PtBuildBox& nb = node_box[i];
+        auto disc = [&](double yc, double radius, PtBuildBox* b) {  // disc of `radius` in the model xz-plane at height yc
+            for (int r = 0; r < 3; r++) {
+                double c = M[4 * r + 1] * yc + M[4 * r + 3];
+                double e = radius * std::sqrt(M[4 * r] * M[4 * r] + M[4 * r + 2] * M[4 * r + 2]);
+                b->lo[r] = std::min(b->lo[r], c - e); b->hi[r] = std::max(b->hi[r], c + e);
+            }
+        };
         double lo[3], hi[3];
+        bool boxed = false;
         switch (t) {
-        case PT_PRIM_SPHERE: lo[0] = lo[1] = lo[2] = -1.0001; hi[0] = hi[1] = hi[2] = 1.0001; break;
+        case PT_PRIM_SPHERE:
+            for (int r = 0; r < 3; r++) {
+                double e = 1.0001 * std::sqrt(M[4 * r] * M[4 * r] + M[4 * r + 1] * M[4 * r + 1] + M[4 * r + 2] * M[4 * r + 2]);
+                nb.lo[r] = M[4 * r + 3] - e; nb.hi[r] = M[4 * r + 3] + e;
+            }
+            boxed = true; break;
+        case PT_PRIM_CYLINDER: nb = pt_bvh_detail::empty_box(); disc(0.5001, 0.5001, &nb); disc(-0.5001, 0.5001, &nb); boxed = true; break;
+        case PT_PRIM_CONE: nb = pt_bvh_detail::empty_box(); disc(0.5001, 1e-4, &nb); disc(-0.5001, 0.5001, &nb); boxed = true; break;
         case PT_PRIM_PLANE: lo[0] = lo[2] = -0.5001; hi[0] = hi[2] = 0.5001; lo[1] = -1e-4; hi[1] = 1e-4; break;
         case PT_PRIM_MESH: case PT_PRIM_KDMESH: for (int k = 0; k < 3; k++) { lo[k] = mesh_box[data].lo[k]; hi[k] = mesh_box[data].hi[k]; } break;
         case PT_PRIM_TRIANGLE: {
@@ -369,12 +391,14 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
             for (int k = 0; k < 3; k++) { lo[k] -= 1e-6 * ext; hi[k] += 1e-6 * ext; }
             break;
         }
-        default: lo[0] = lo[1] = lo[2] = -0.5001; hi[0] = hi[1] = hi[2] = 0.5001; break;  // cube, cylinder, cone
+        default: lo[0] = lo[1] = lo[2] = -0.5001; hi[0] = hi[1] = hi[2] = 0.5001; break;  // cube
         }
-        pt_transform_box(&s->trans[16 * (size_t)i], lo, hi, &node_box[i]);
-        pt_pad_box(&node_box[i], 1e-9);
+        if (!boxed) pt_transform_box(M, lo, hi, &nb);
+        pt_pad_box(&nb, 1e-9);
     }
-    PtBvhRef tlas = pt_bvh_build(node_box.data(), nullptr, n, 2, bvh, items);
+    int tlas_leaf = 1;  // primitive tests (f64, ~200 instructions) cost far more than a node visit: measured best on big-scene
+    if (const char* e = getenv("PORTRAYER_TLAS_LEAF")) tlas_leaf = std::max(1, atoi(e));
+    PtBvhRef tlas = pt_bvh_build(node_box.data(), nullptr, n, tlas_leaf, bvh, items);
 
     // ---- k-d tree (reference structure, KD mode)
     std::vector<PtKdNode> kdn;
