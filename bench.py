@@ -44,9 +44,9 @@ def algorithmic_bytes(st, n_lights, pixels, traversal):
     """B_ray = 56 + node bytes + 104 n_analytic + 72 n_tri + 48 n_bbox + H (168 + 80 + 120 L),
     summed over all rays of one launch, plus 3 B written and 24 B of background read per pixel. A k-d split
     record is 16 B (plane + two child indices); a node of this build's two-child bounding-volume tree is
-    104 B (two f64 boxes + two child references)."""
+    56 B (two f32 boxes + two child references)."""
     rays = st["primary"] + st["shadow"] + st["reflect"] + st["refract"]
-    node_bytes = 16 if traversal == "kd" else 104
+    node_bytes = 16 if traversal == "kd" else 56
     return (56 * rays + node_bytes * st["n_inner"] + 104 * st["n_analytic"] + 72 * st["n_tri"] + 48 * st["n_bbox"]
             + st["hits"] * (168 + 80 + 120 * n_lights) + 27 * pixels)
 

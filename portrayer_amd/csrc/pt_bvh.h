@@ -40,6 +40,18 @@ inline double half_area(const PtBuildBox& b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
+// f64 -> f32 rounded toward -inf / +inf (boxes may only grow)
+inline float round_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+inline float round_up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
 struct Builder {
     const PtBuildBox* boxes;
     std::vector<uint32_t> order;  // permutation of local indices
@@ -114,8 +126,11 @@ struct Builder {
         PtBvhRef l = build(b, mid, level + 1);
         PtBvhRef r = build(mid, e, level + 1);
         PtBvhNode& nd = (*nodes)[idx];
-        for (int k = 0; k < 3; k++) { nd.lo0[k] = l.box.lo[k]; nd.hi0[k] = l.box.hi[k]; nd.lo1[k] = r.box.lo[k]; nd.hi1[k] = r.box.hi[k]; }
-        nd.child0 = l.child; nd.child1 = r.child;
+        for (int k = 0; k < 3; k++) {
+            nd.lo0[k] = round_down(l.box.lo[k]); nd.hi0[k] = round_up(l.box.hi[k]);
+            nd.lo1[k] = round_down(r.box.lo[k]); nd.hi1[k] = round_up(r.box.hi[k]);
+        }
+        nd.child0 = l.child; nd.child1 = r.child; nd.pad[0] = nd.pad[1] = 0;
         PtBvhRef out;
         out.child = (uint32_t)idx; out.box = box; out.depth = 1 + std::max(l.depth, r.depth);
         return out;

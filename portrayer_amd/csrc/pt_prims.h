@@ -132,6 +132,70 @@ PT_HD bool pt_cone_hit(const PtRay& r, double start, double end, double* t_out, 
     return found;
 }
 
+// All five analytic primitives in ONE instruction stream, so that a wavefront whose lanes hold
+// different primitive types does not run five separate routines one after the other.
+//
+// Every unit primitive is a subset of the same two kinds of sub-test, taken in the reference's order
+// with a shrinking range end:
+//   1. a quadric body: sphere (sphere.rs:48-52), cylinder side (cylinder.rs:44-60), cone side
+//      (cone.rs:58-76) — only the three coefficients differ, the root search is shared;
+//   2. up to six axis planes +x, -x, +y, -y, +z, -z at +-0.5: the cube's faces (cube.rs:46-83), the
+//      cylinder's caps (cylinder.rs:94-104), the cone's base (cone.rs:131-148), and the Plane
+//      primitive itself (plane.rs:35-53, the +y slot at height 0). Each is t = (h - o_a) / d_a, which
+//      is bit-identical to the reference's -((o - P).n) / (d.n) for an axis-aligned unit normal
+//      (x - y == -(y - x) and x / -y == -(x / y) exactly), followed by the type's own acceptance test.
+// `part` is the tag pt_prim_surface() expects.
+PT_HD bool pt_unit_prim_hit(uint32_t type, const PtRay& r, double start, double end, double* t_out, uint32_t* part) {
+    bool found = false;
+    if (type == PT_SPHERE || type == PT_CYLINDER || type == PT_CONE) {
+        double a, b, c;
+        if (type == PT_SPHERE) {
+            a = pt_dot(r.d, r.d);
+            b = 2.0 * pt_dot(r.o, r.d);
+            c = pt_dot(r.o, r.o) - 1.0;
+        } else if (type == PT_CYLINDER) {
+            a = r.d.x * r.d.x + r.d.z * r.d.z;
+            b = 2.0 * r.o.x * r.d.x + 2.0 * r.o.z * r.d.z;
+            c = r.o.x * r.o.x + r.o.z * r.o.z - 0.25;
+        } else {
+            const double h_sqr = 1.0, r_sqr = 0.25, HEIGHT = 1.0;
+            PtVec3 o = r.o, d = r.d;
+            a = 4.0 * d.y * d.y * r_sqr - 4.0 * h_sqr * (d.x * d.x + d.z * d.z);
+            b = -8.0 * h_sqr * (d.x * o.x + d.z * o.z) - 4.0 * r_sqr * (d.y * HEIGHT - 2.0 * d.y * o.y);
+            c = -4.0 * h_sqr * (o.x * o.x + o.z * o.z) + r_sqr * (h_sqr - 4.0 * HEIGHT * o.y + 4.0 * o.y * o.y);
+        }
+        double t;
+        if (pt_first_root(a, b, c, start, end, &t)) {  // first root only (quirk Q1)
+            double y = r.o.y + r.d.y * t;
+            if (type == PT_SPHERE || !(y > 0.5 || y < -0.5)) { end = t; *t_out = t; *part = 0; found = true; }
+        }
+    }
+    // slots the type uses, bit k = slot k (+x, -x, +y, -y, +z, -z)
+    const uint32_t slots = type == PT_CUBE ? 0x3Fu : (type == PT_CYLINDER ? 0x0Cu : (type == PT_CONE ? 0x08u : (type == PT_PLANE ? 0x04u : 0u)));
+    const double radius = 0.5 + PT_EPSILON;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (!(slots & (1u << k))) continue;
+        const int axis = k >> 1;
+        double h = (k & 1) ? -0.5 : 0.5;
+        if (type == PT_PLANE) h = 0.0;
+        double o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
+        double d = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
+        double t = (h - o) / d;
+        if (!pt_in_range(start, end, t)) continue;
+        PtVec3 p = pt_ray_at(r, t);
+        bool ok;
+        if (type == PT_CUBE) ok = -radius <= p.x && p.x <= radius && -radius <= p.y && p.y <= radius && -radius <= p.z && p.z <= radius;
+        else if (type == PT_PLANE) ok = -radius <= p.x && p.x <= radius && -radius <= p.z && p.z <= radius;
+        else ok = !((p.x * p.x + p.z * p.z) > 0.25);
+        if (ok) {
+            end = t; *t_out = t; found = true;
+            *part = type == PT_CUBE ? (uint32_t)k : (type == PT_CYLINDER ? (uint32_t)(k - 1) : (type == PT_CONE ? 1u : 0u));
+        }
+    }
+    return found;
+}
+
 // triangle.rs:38-80 (Cramer's rule; test order t, gamma, beta). v = a, b, c as 9 doubles.
 PT_HD bool pt_triangle_hit(const double* v, const PtRay& r, double start, double end, double* t_out, double* beta_out, double* gamma_out) {
     double a = v[0] - v[3], b = v[1] - v[4], c = v[2] - v[5];

@@ -23,10 +23,15 @@ enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2 };
 // items[first .. first + count), first in bits 30..3, count - 1 in bits 2..0 (1 <= count <= 8).
 #define PT_REF_LEAF 0x80000000u
 #define PT_REF_EMPTY 0xFFFFFFFFu
+// Boxes are f32, rounded OUTWARD at build time: the tree only decides which candidates are tested
+// (every accepted hit is produced by the f64 reference arithmetic of the primitive tests), so its
+// own arithmetic may be single precision as long as it never rejects a box the f64 ray touches
+// (pt_slab32 in pt_trace.h carries the error bounds).
 struct PtBvhNode {
-    double lo0[3], hi0[3], lo1[3], hi1[3];
+    float lo0[3], hi0[3], lo1[3], hi1[3];
     uint32_t child0, child1;
-};  // 104 bytes
+    uint32_t pad[2];
+};  // 64 bytes = four 16-byte loads
 
 struct PtKdNode {
     double plane;          // coordinate of the separating plane on `axis`

@@ -160,8 +160,13 @@ PT_HD PtVec3 pt_light_position(const PtRenderArgs& a, const PtLane& L, const dou
 
 // Runs the lane's interpreter until it needs a ray traced (L.has_ray) or its pixel is finished
 // (L.work == PT_IDLE). `hit` is the result of the ray the lane traced last.
+#ifdef PT_ADVANCE_NOINLINE  // measured slower at every occupancy (profiles/r01/notes.md)
+#define PT_ADVANCE_ATTR PT_NOINLINE
+#else
+#define PT_ADVANCE_ATTR PT_HD
+#endif
 template <bool STATS>
-PT_HD void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt) {
+PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt) {
     const PtSceneView& sc = a.scene;
     L.has_ray = false;
     PtVec3 value = pt_v3(0.0, 0.0, 0.0);  // colour being returned to the parent frame

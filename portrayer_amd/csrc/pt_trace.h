@@ -44,47 +44,78 @@ PT_HD double pt_pop_f64(const PtStack& s, int& sp) {
     return c.d;
 }
 
-// Slab test of one child box against [0, tmax]. NaNs from 0 * inf drop out of fmin/fmax
-// (minNum semantics); boxes are padded at build time so rounding here cannot lose a hit.
-PT_HD bool pt_slab(const double* lo, const double* hi, PtVec3 o, PtVec3 inv, double tmax, double* tnear) {
-    double x0 = (lo[0] - o.x) * inv.x, x1 = (hi[0] - o.x) * inv.x;
-    double y0 = (lo[1] - o.y) * inv.y, y1 = (hi[1] - o.y) * inv.y;
-    double z0 = (lo[2] - o.z) * inv.z, z1 = (hi[2] - o.z) * inv.z;
-    double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), 0.0));
-    double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), tmax));
-    *tnear = tn;
-    return tn <= tf * 1.0000000000000004;
+// Single-precision ray for the tree walk, with the bounds that keep the f32 slab test conservative:
+// o_hi >= o >= o_lo component-wise (the f64 origin lies between them), inv = fl32(1 / d).
+struct PtRay32 {
+    float ohx, ohy, ohz, olx, oly, olz, ix, iy, iz;
+};
+PT_HD PtRay32 pt_ray32(const PtRay& r) {
+    PtRay32 q;
+    float x = (float)r.o.x, y = (float)r.o.y, z = (float)r.o.z;
+    const float e = 2.4e-7f;  // > 2^-23: covers the rounding of the conversion and of the bound itself
+    float ex = fabsf(x) * e + 1e-37f, ey = fabsf(y) * e + 1e-37f, ez = fabsf(z) * e + 1e-37f;
+    q.ohx = x + ex; q.ohy = y + ey; q.ohz = z + ez;
+    q.olx = x - ex; q.oly = y - ey; q.olz = z - ez;
+    q.ix = (float)(1.0 / r.d.x); q.iy = (float)(1.0 / r.d.y); q.iz = (float)(1.0 / r.d.z);
+    return q;
 }
 
-// Generic walk of the build's two-child tree. leaf(first, count, sp) tests the items and returns
-// true to stop the walk (any-hit). `tmax` is re-read after every leaf so shrinking it culls.
+// Slab test of one child box against [0, tmax] in f32. Conservative by construction: the lower
+// planes are measured from o_hi and the upper planes from o_lo (so every numerator errs towards a
+// longer overlap for either sign of the direction), the final interval is widened by 2^-20 relative
+// (sub + mul + reciprocal roundings are < 2^-22), NaNs (0 * inf) fall out of fminf / fmaxf, and the
+// comparison is written so that an unordered result accepts the box.
+PT_HD bool pt_slab32(const float* lo, const float* hi, const PtRay32& q, float tmax, float* tnear) {
+    float x0 = (lo[0] - q.ohx) * q.ix, x1 = (hi[0] - q.olx) * q.ix;
+    float y0 = (lo[1] - q.ohy) * q.iy, y1 = (hi[1] - q.oly) * q.iy;
+    float z0 = (lo[2] - q.ohz) * q.iz, z1 = (hi[2] - q.olz) * q.iz;
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    const float w = 9.6e-7f;
+    tn = fmaxf(tn - fabsf(tn) * w, 0.0f);
+    tf = fminf(tf + fabsf(tf) * w, tmax);
+    *tnear = tn;
+    return !(tn > tf);
+}
+
+// Generic walk of the build's two-child tree, "while-while": every lane first descends through inner
+// nodes until it holds a leaf (or has nothing left), and only then do the lanes test their leaves
+// together — the leaf work (f64 primitive tests) is the expensive part and should run with as many
+// lanes active as possible. leaf(first, count, sp) tests the items and returns true to stop the walk
+// (any-hit). `tmax` is re-read after every leaf so shrinking it culls.
 template <bool STATS, class Leaf>
 PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, const double& tmax,
                        const PtStack& stk, int sp0, Leaf&& leaf, PtCounters* cnt) {
     if (root == PT_REF_EMPTY) return false;
     int sp = sp0;
-    PtVec3 inv = pt_v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    const PtRay32 q = pt_ray32(r);
     uint32_t cur = root;
     for (;;) {
-        if (!(cur & PT_REF_LEAF)) {
+        while (!(cur & PT_REF_LEAF)) {
             const PtBvhNode& n = nodes[cur];
             if (STATS) cnt->n_inner++;
-            double t0, t1;
-            bool h0 = pt_slab(n.lo0, n.hi0, r.o, inv, tmax, &t0);
-            bool h1 = pt_slab(n.lo1, n.hi1, r.o, inv, tmax, &t1);
+            // tmax rounded up: (float) rounds to nearest, one more relative step covers it (inf stays inf)
+            float tm = (float)tmax; tm = tm + fabsf(tm) * 2.4e-7f;
+            float t0, t1;
+            bool h0 = pt_slab32(n.lo0, n.hi0, q, tm, &t0);
+            bool h1 = pt_slab32(n.lo1, n.hi1, q, tm, &t1);
             uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
                 if (sp + 1 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
                 pt_push(stk, sp, swap ? c0 : c1);
                 cur = swap ? c1 : c0;
-                continue;
-            } else if (h0) { cur = c0; continue; }
-            else if (h1) { cur = c1; continue; }
-        } else {
-            if (STATS) cnt->n_leaf++;
-            if (leaf((cur & ~PT_REF_LEAF) >> 3, (cur & 7u) + 1u, sp)) return true;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else {
+                if (sp == sp0) return false;
+                cur = pt_pop(stk, sp);
+            }
         }
+        if (STATS) cnt->n_leaf++;
+        if (leaf((cur & ~PT_REF_LEAF) >> 3, (cur & 7u) + 1u, sp)) return true;
         if (sp == sp0) return false;
         cur = pt_pop(stk, sp);
     }
@@ -110,11 +141,9 @@ PT_HD bool pt_test_node(const PtSceneView& sc, uint32_t node, const PtRay& ray, 
     uint32_t part = 0;
     bool hit;
     switch (type) {
-    case PT_SPHERE: hit = pt_sphere_hit(local, start, pt_cand_end(best, node, 0), &t); break;
-    case PT_PLANE: hit = pt_plane_hit(local, start, pt_cand_end(best, node, 0), &t); break;
-    case PT_CUBE: hit = pt_cube_hit(local, start, pt_cand_end(best, node, 0), &t, &part); break;
-    case PT_CYLINDER: hit = pt_cylinder_hit(local, start, pt_cand_end(best, node, 0), &t, &part); break;
-    case PT_CONE: hit = pt_cone_hit(local, start, pt_cand_end(best, node, 0), &t, &part); break;
+    case PT_SPHERE: case PT_PLANE: case PT_CUBE: case PT_CYLINDER: case PT_CONE:
+        hit = pt_unit_prim_hit(type, local, start, pt_cand_end(best, node, 0), &t, &part);
+        break;
     case PT_TRIANGLE: {  // stand-alone triangle, stored after the mesh triangles
         double beta, gamma;
         if (STATS) cnt->n_tri++;
