@@ -171,6 +171,13 @@ uint64_t pt_compact_bytes(const pt_render_params *params);
 /* Scatters the gathered compact buffers (rank-major) into a row-major image on the device. */
 int pt_untile_device(pt_context *ctx, const pt_render_params *params, const void *d_gathered, void *d_rgb, void *hip_stream);
 
+/* Host-side view of the tile partition (no GPU needed): pixel of work slot `slot` of rank `rank`
+ * (slot = local tile * 64 + position in the 8x8 tile). Returns 1 and fills x, y; 0 for a padding slot
+ * (outside the slice / beyond the last tile); < 0 on bad arguments. */
+int pt_tile_slot_pixel(const pt_render_params *params, uint32_t rank, uint32_t slot, uint32_t *x, uint32_t *y);
+/* Host version of pt_untile_device: gathered = tile_ranks x pt_compact_bytes(), rank-major. */
+int pt_untile_host(const pt_render_params *params, const uint8_t *gathered, uint8_t *rgb);
+
 /* Device-side helpers used by the measurement harness. */
 int pt_device_alloc(pt_context *ctx, uint64_t bytes, void **out);
 int pt_device_free(pt_context *ctx, void *ptr);

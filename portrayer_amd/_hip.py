@@ -75,7 +75,7 @@ class PtStats(C.Structure):
 _lib: Optional[C.CDLL] = None
 
 EXPORTS = ["pt_abi_version", "pt_device_count", "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_scene_upload",
-           "pt_render", "pt_render_device", "pt_render_finish", "pt_compact_bytes", "pt_untile_device", "pt_device_alloc",
+           "pt_render", "pt_render_device", "pt_render_finish", "pt_compact_bytes", "pt_untile_device", "pt_tile_slot_pixel", "pt_untile_host", "pt_device_alloc",
            "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_synchronize", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
            "pt_test_math"]
 
@@ -106,6 +106,10 @@ def lib() -> C.CDLL:
         l.pt_compact_bytes.argtypes = [C.POINTER(PtRenderParams)]
         l.pt_untile_device.restype = C.c_int
         l.pt_untile_device.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), C.c_void_p, C.c_void_p, C.c_void_p]
+        l.pt_tile_slot_pixel.restype = C.c_int
+        l.pt_tile_slot_pixel.argtypes = [C.POINTER(PtRenderParams), C.c_uint32, C.c_uint32, _up, _up]
+        l.pt_untile_host.restype = C.c_int
+        l.pt_untile_host.argtypes = [C.POINTER(PtRenderParams), _u8p, _u8p]
         l.pt_device_alloc.restype = C.c_int
         l.pt_device_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         l.pt_device_free.restype = C.c_int

@@ -642,6 +642,41 @@ extern "C" int pt_untile_device(pt_context* c, const pt_render_params* p, const 
     return PT_OK;
 }
 
+static bool pt_params_to_args(const pt_render_params* p, uint32_t rank, PtRenderArgs* a) {
+    if (!p || p->width == 0 || p->height == 0 || p->tile_ranks == 0 || rank >= p->tile_ranks) return false;
+    if (p->slice.x0 >= p->width || p->slice.x1 >= p->width || p->slice.y0 >= p->height || p->slice.y1 >= p->height) return false;
+    memset(a, 0, sizeof *a);
+    a->width = p->width; a->height = p->height;
+    a->x0 = p->slice.x0; a->y0 = p->slice.y0; a->x1 = p->slice.x1; a->y1 = p->slice.y1;
+    a->tile_rank = rank; a->tile_ranks = p->tile_ranks;
+    return true;
+}
+
+extern "C" int pt_tile_slot_pixel(const pt_render_params* p, uint32_t rank, uint32_t slot, uint32_t* x, uint32_t* y) {
+    PtRenderArgs a;
+    if (!x || !y || !pt_params_to_args(p, rank, &a)) return PT_ERR_ARGUMENT;
+    if (p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0 || slot >= pt_slots_per_rank(p)) return 0;
+    return pt_work_to_pixel(a, slot, x, y) ? 1 : 0;
+}
+
+extern "C" int pt_untile_host(const pt_render_params* p, const uint8_t* gathered, uint8_t* rgb) {
+    PtRenderArgs a;
+    if (!gathered || !rgb || !pt_params_to_args(p, 0, &a)) return PT_ERR_ARGUMENT;
+    if (p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0) return PT_OK;
+    uint32_t per = pt_slots_per_rank(p);
+    for (uint32_t r = 0; r < p->tile_ranks; r++) {
+        a.tile_rank = r;
+        for (uint32_t w = 0; w < per; w++) {
+            uint32_t x, y;
+            if (!pt_work_to_pixel(a, w, &x, &y)) continue;
+            const uint8_t* s = gathered + 3 * ((size_t)r * per + w);
+            uint8_t* d = rgb + 3 * ((size_t)y * p->width + x);
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+        }
+    }
+    return PT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Harness helpers
 // ------------------------------------------------------------------------------------------------

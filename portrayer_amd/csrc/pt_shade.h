@@ -25,6 +25,13 @@
 #define PT_FRAME_SLOTS 13
 #define PT_MAX_DEPTH 10  // material.rs:12
 #define PT_IDLE 0xFFFFFFFFu
+// A compiler-only fence: stops hipcc from hoisting the loads of one interpreter state above the
+// stores of the previous one (register pressure), costs no instruction.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_STATE_FENCE)
+#define PT_FENCE asm volatile("" ::: "memory")
+#else
+#define PT_FENCE
+#endif
 
 enum { PT_JITTER_CENTRE = 0, PT_JITTER_RNG = 1 };
 enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_AFTER_LIGHTS = 4 };
@@ -239,6 +246,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         }
         switch (L.stage) {
         case PT_ST_NEW_SAMPLE: {
+            PT_FENCE;
             if (L.sample >= a.samples) {
                 pt_finish_pixel(a, L);
                 L.work = PT_IDLE;
@@ -258,6 +266,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             return;
         }
         case PT_ST_CLOSEST_DONE: {  // ray.rs:139-148
+            PT_FENCE;
             if (hit.node == PT_NO_HIT) { value = pt_background(a, L.x, L.y); returning = true; continue; }
             if (STATS) cnt->hits++;
             // flat_scene.rs:85-95: rebuild the model-space hit, bring point and normal to world space
@@ -282,14 +291,17 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             } else {
                 pt_prim_surface(type, hit.sub, local, hit.t, &p, &n);
             }
+            PT_FENCE;
             PtVec3 P = pt_xform_point(sc.fwd + 12 * (size_t)hit.node, p);
+            fr.store3(L.depth, 3, P);
+            PT_FENCE;
             PtVec3 Nw = pt_xform_dir(sc.nrm + 9 * (size_t)hit.node, 3, n);
             PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
+            fr.store3(L.depth, 6, N);
+            PT_FENCE;
             const double* m = sc.materials + 10 * (size_t)mat;
             PtVec3 color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * pt_v3(m[0], m[1], m[2]);  // material.rs:148
             fr.store3(L.depth, 0, L.ray.d);
-            fr.store3(L.depth, 3, P);
-            fr.store3(L.depth, 6, N);
             fr.store3(L.depth, 9, color);
             fr.store_tag(L.depth, mat, 0);
             L.light = 0;
@@ -297,6 +309,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             continue;
         }
         case PT_ST_LIGHT: {  // material.rs:149-179
+            PT_FENCE;
             if (L.light >= sc.n_lights) { L.stage = PT_ST_AFTER_LIGHTS; continue; }
             const double* light = sc.lights + 15 * (size_t)L.light;
             bool is_area;
@@ -312,6 +325,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             return;
         }
         case PT_ST_SHADOW_DONE: {  // material.rs:179-210
+            PT_FENCE;
             if (hit.node == PT_NO_HIT) {
                 const double* light = sc.lights + 15 * (size_t)L.light;
                 bool is_area;
@@ -343,6 +357,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             continue;
         }
         default: {  // PT_ST_AFTER_LIGHTS: material.rs:216-243
+            PT_FENCE;
             uint32_t mat, fstage;
             fr.load_tag(L.depth, &mat, &fstage);
             const double* m = sc.materials + 10 * (size_t)mat;
