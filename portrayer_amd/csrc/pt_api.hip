@@ -28,7 +28,7 @@
 
 #define PT_BLOCK 256
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 2  // waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument)
+#define PT_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument); measured best, profiles/r01/notes.md
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -65,7 +65,6 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
     PtLane L;
     L.work = PT_IDLE; L.has_ray = false; L.ray_any = false;
     L.x = L.y = L.sample = L.stage = L.light = L.draw = 0; L.depth = 0;
-    L.sum = pt_v3(0.0, 0.0, 0.0);
     L.ray.o = L.ray.d = pt_v3(0.0, 0.0, 0.0);
     PtHit hit;
     hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
@@ -525,7 +524,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     uint32_t grid = 0;
     PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
-    int rc = pt_reserve(c, c->frames, (size_t)a.n_lanes * (PT_MAX_DEPTH + 1) * PT_FRAME_SLOTS * sizeof(double));
+    int rc = pt_reserve(c, c->frames, (size_t)a.n_lanes * PT_FRAME_DEPTHS * PT_FRAME_SLOTS * sizeof(double));
     if (rc) return rc;
     if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters)))) return rc;
     a.frames = (double*)c->frames.p;

@@ -18,12 +18,15 @@
 //   slots 0-2 ray direction D (later: reflected colour Cr), 3-5 hit point P (3: Schlick
 //   reflectance once the refracted ray is in flight), 6-8 unit normal N, 9-11 colour so far,
 //   12 {material, frame stage}.
+// Depth PT_SUM_DEPTH (one past the deepest frame) slots 0-2 hold the pixel's running sample sum.
 #pragma once
 
 #include "pt_trace.h"
 
 #define PT_FRAME_SLOTS 13
 #define PT_MAX_DEPTH 10  // material.rs:12
+#define PT_SUM_DEPTH (PT_MAX_DEPTH + 1)
+#define PT_FRAME_DEPTHS (PT_MAX_DEPTH + 2)
 #define PT_IDLE 0xFFFFFFFFu
 // A compiler-only fence: stops hipcc from hoisting the loads of one interpreter state above the
 // stores of the previous one (register pressure), costs no instruction.
@@ -62,7 +65,6 @@ struct PtLane {
     uint32_t work;  // slot index in this launch, PT_IDLE when the lane has no pixel
     uint32_t x, y, sample, stage, light, draw;
     int32_t depth;
-    PtVec3 sum;
     PtRay ray;
     bool has_ray, ray_any;
 };
@@ -111,6 +113,15 @@ PT_HD PtRay pt_camera_ray(const PtCamera& c, double x, double y) {  // camera.rs
     return r;
 }
 
+// pow is the only libm call on the path (gamma render.rs:47, specular material.rs:200). Kept out of
+// line: the device library's f64 pow needs more registers than the rest of the interpreter, and one
+// shared copy lets the allocator size everything else for a higher occupancy.
+#ifdef PT_POW_INLINE
+PT_HD double pt_pow(double x, double y) { return pow(x, y); }
+#else
+PT_NOINLINE double pt_pow(double x, double y) { return pow(x, y); }
+#endif
+
 PT_HD uint8_t pt_to_u8(double c) {  // render.rs:143-147: `as u8` saturates, NaN -> 0
     double v = c * 255.0;
     if (!(v > 0.0)) return 0;
@@ -135,12 +146,12 @@ PT_HD bool pt_refracted_direction(PtVec3 ray_dir, PtVec3 normal, double eta, PtV
     return true;
 }
 
-PT_HD void pt_finish_pixel(const PtRenderArgs& a, const PtLane& L) {  // render.rs:45-50, :143-147
-    PtVec3 color = L.sum / (double)a.samples;
+PT_HD void pt_finish_pixel(const PtRenderArgs& a, const PtLane& L, PtVec3 sum) {  // render.rs:45-50, :143-147
+    PtVec3 color = sum / (double)a.samples;
     size_t idx = a.compact ? (size_t)L.work : (size_t)L.y * a.width + L.x;
     if (a.linear) { double* o = a.linear + 3 * idx; o[0] = color.x; o[1] = color.y; o[2] = color.z; }
     const double g = 1.0 / PT_GAMMA;
-    double ch[3] = {pow(color.x, g), pow(color.y, g), pow(color.z, g)};
+    double ch[3] = {pt_pow(color.x, g), pt_pow(color.y, g), pt_pow(color.z, g)};
     uint8_t* o = a.rgb + 3 * idx;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -183,7 +194,8 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             // `value` = Ray::color() of the ray cast at depth L.depth
             returning = false;
             if (L.depth == 0) {  // render.rs:36-43: samples summed in ascending order
-                L.sum = L.sample == 0 ? value : L.sum + value;
+                if (L.sample != 0) value = fr.load3(PT_SUM_DEPTH, 0) + value;
+                fr.store3(PT_SUM_DEPTH, 0, value);
                 L.sample++;
                 L.stage = PT_ST_NEW_SAMPLE;
                 continue;
@@ -248,7 +260,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         case PT_ST_NEW_SAMPLE: {
             PT_FENCE;
             if (L.sample >= a.samples) {
-                pt_finish_pixel(a, L);
+                pt_finish_pixel(a, L, fr.load3(PT_SUM_DEPTH, 0));
                 L.work = PT_IDLE;
                 return;
             }
@@ -346,7 +358,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 if (ks.x > PT_EPSILON || ks.y > PT_EPSILON || ks.z > PT_EPSILON) {
                     PtVec3 view = -ray_dir;
                     PtVec3 half = pt_normalized(view + light_dir);
-                    double nhs = pow(fmax(pt_dot(N, half), 0.0), 4.0 * m[6]);
+                    double nhs = pt_pow(fmax(pt_dot(N, half), 0.0), 4.0 * m[6]);
                     specular = (ks * lcol) * nhs;
                 }
                 color = color + (diffuse + specular) / attenuation;
