@@ -37,7 +37,8 @@
 template <int MODE, bool STATS>
 __device__ __forceinline__ void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const PtStack& stk, PtCounters* cnt) {
     if (MODE == PT_MODE_KD) pt_trace_kd<STATS>(sc, ray, any, hit, stk, cnt);
-    else pt_trace_flat<STATS>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
+    else pt_trace_flat<STATS, true>(sc, ray, any, hit, stk, cnt);
 }
 
 __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCounters& c) {
@@ -450,8 +451,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.tlas_root = tlas.child; v.pad0 = 0;
     v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
     v.kd_extent = kd_extent;
-    v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : PT_MODE_FLAT;
-    int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + max_blas_depth + 2 : tlas.depth + max_blas_depth + 2;
+    v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : PT_MODE_FLAT);
+    int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + max_blas_depth + 2 : tlas.depth + max_blas_depth + 4;
     v.stack_cap = std::max(cap, 8);
     if ((size_t)v.stack_cap * PT_BLOCK * 4 > 64 * 1024) return pt_fail(c, PT_ERR_SCENE, "traversal stack would not fit in LDS (tree too deep)");
     c->have_scene = true;
@@ -500,6 +501,7 @@ static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream,
 }
 
 static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
+    if (a.scene.mode == PT_MODE_FLAT_NOMESH) return stats ? pt_launch<PT_MODE_FLAT_NOMESH, true>(a, n_cu, stream, grid, launch) : pt_launch<PT_MODE_FLAT_NOMESH, false>(a, n_cu, stream, grid, launch);
     if (a.scene.mode == PT_MODE_KD) return stats ? pt_launch<PT_MODE_KD, true>(a, n_cu, stream, grid, launch) : pt_launch<PT_MODE_KD, false>(a, n_cu, stream, grid, launch);
     return stats ? pt_launch<PT_MODE_FLAT, true>(a, n_cu, stream, grid, launch) : pt_launch<PT_MODE_FLAT, false>(a, n_cu, stream, grid, launch);
 }
@@ -747,7 +749,8 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     PT_HIP(c, hipMemcpy(d_d, directions, n * 24, hipMemcpyHostToDevice));
     size_t lds = (size_t)c->view.stack_cap * PT_BLOCK * 4;
     dim3 grid((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK));
-    if (c->view.mode == PT_MODE_KD) hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_KD>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
+    if (c->view.mode == PT_MODE_FLAT_NOMESH) hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_FLAT_NOMESH>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
+    else if (c->view.mode == PT_MODE_KD) hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_KD>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
     else hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_FLAT>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
     PT_HIP(c, hipGetLastError());
     PT_HIP(c, hipDeviceSynchronize());

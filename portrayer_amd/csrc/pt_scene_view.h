@@ -16,7 +16,7 @@
 
 #include "pt_math.h"
 
-enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2 };
+enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2, PT_MODE_FLAT_NOMESH = 3 };  // 3: FLAT for scenes without mesh instances
 
 // Two children per record so one fetch decides both sides. A child reference is one 32-bit word
 // (one traversal-stack slot): bit 31 clear = inner node index; bit 31 set = leaf with
