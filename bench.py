@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="testing: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare rank 0's assembled image with a single-GPU render")
+    ap.add_argument("--force-dist", action="store_true", help="testing: take the torch.distributed path even with one rank")
+    ap.add_argument("--share", type=int, default=1, help="testing: render only rank 0's tiles of an N-rank partition (no gather)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,12 +77,15 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
     dist = torch = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         # torch first: its bundled HIP runtime and ours share a SONAME; loaded in this order the
         # process ends up with ONE runtime.
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     import ctypes as C
@@ -112,11 +117,11 @@ def main():
     check(lib.pt_copy_to_device(ctx, d_bg, bg.ctypes.data_as(C.c_void_p), bg.nbytes), "pt_copy_to_device")
 
     def params(stats):
-        return H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, rank, world, 1 if stats else 0)
+        return H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, rank, world if args.share == 1 else args.share, 1 if stats else 0)
 
     p = params(False)
     compact_bytes = int(lib.pt_compact_bytes(C.byref(p)))
-    if world > 1:
+    if use_dist:
         dev = torch.device("cpu") if args.backend == "gloo" else torch.device(f"cuda:{device}")
         if args.backend == "nccl":
             torch.cuda.set_device(device)
@@ -124,16 +129,16 @@ def main():
         gathered_t = torch.empty(compact_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None
         gather_list = list(gathered_t.chunk(world)) if rank == 0 else None  # views: the gather lands rank-major in one buffer
     d_mine = C.c_void_p()
-    if world > 1 and args.backend == "gloo":
+    if use_dist and args.backend == "gloo":
         check(lib.pt_device_alloc(ctx, compact_bytes, C.byref(d_mine)), "pt_device_alloc")
     d_full = C.c_void_p(); d_gath = C.c_void_p()
     if rank == 0:
         check(lib.pt_device_alloc(ctx, w * h * 3, C.byref(d_full)), "pt_device_alloc")
-        if world > 1 and args.backend == "gloo":
+        if use_dist and args.backend == "gloo":
             check(lib.pt_device_alloc(ctx, compact_bytes * world, C.byref(d_gath)), "pt_device_alloc")
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             if args.backend == "nccl":
                 torch.cuda.synchronize()
@@ -142,7 +147,7 @@ def main():
         """One frame: render own tiles -> (gather -> untile on rank 0). Returns this rank's pt_stats."""
         pp = params(stats)
         st = H.PtStats()
-        if world == 1:
+        if not use_dist:
             target, compact = d_full, 0
         elif args.backend == "nccl":
             target, compact = C.c_void_p(mine_t.data_ptr()), 1  # render straight into the tensor RCCL sends from
@@ -150,7 +155,7 @@ def main():
             target, compact = d_mine, 1
         check(lib.pt_render_device(ctx, C.byref(cam), d_bg, C.byref(pp), compact, target, None), "pt_render_device")
         check(lib.pt_render_finish(ctx, C.byref(st)), "pt_render_finish")  # waits for the kernel (HIP event)
-        if world > 1:
+        if use_dist:
             if args.backend == "gloo":
                 check(lib.pt_copy_from_device(ctx, C.c_void_p(mine_t.data_ptr()), d_mine, compact_bytes), "pt_copy_from_device")
             dist.gather(mine_t, gather_list, dst=0)  # the single collective of the frame
@@ -171,7 +176,7 @@ def main():
         raise RuntimeError("traversal stack overflow")
     keys = ["primary", "shadow", "reflect", "refract", "hits", "n_inner", "n_leaf", "n_analytic", "n_tri", "n_bbox"]
     total = dict(counts)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([counts[k] for k in keys], dtype=torch.int64, device=mine_t.device)
         dist.all_reduce(t)
         for k, x in zip(keys, t.tolist()):
@@ -187,7 +192,7 @@ def main():
         kernel_ms.append(step()["kernel_ms"])
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=mine_t.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -202,7 +207,7 @@ def main():
 
     if rank == 0:
         mean_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-        mine_bytes = algorithmic_bytes(counts, n_lights, compact_bytes // 3 if world > 1 else w * h, args.traversal)
+        mine_bytes = algorithmic_bytes(counts, n_lights, compact_bytes // 3 if use_dist else w * h, args.traversal)
         achieved = mine_bytes / mean_kernel_s / 1e9
         out = {
             "metric": "Mray/s (primary+shadow+secondary) at 1920x1080 SAMPLES=64",
@@ -234,10 +239,14 @@ def main():
             out["config"]["host_buffer_path"] = {"ms_per_frame": hst["total_ms"], "Mray_per_s": rays_frame / hst["total_ms"] / 1e3}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(example, n, w, h, args.traversal)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    else:
+        out = None
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)  # the one JSON line, last thing on rank 0's stdout
 
 
 def cpu_baseline(example, n, w, h, traversal):

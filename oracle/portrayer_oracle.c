@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <unistd.h>
 
+#define PO_SAMPLE_CHUNK 8
+
 typedef struct { po_vec3 o, d; } ray_t;          /* ray.rs:102-108 */
 typedef struct { double t; po_vec3 p, n; } hit_t; /* ray.rs:10-36 (tex_coord / TBN are "next") */
 
@@ -859,8 +861,11 @@ static void render_pixel(const job_t *j, uint32_t x, uint32_t y, po_stats *st) {
     size_t pix = (size_t)y * p->width + x;
     const double *b = p->background_rows ? j->bg + 3 * (size_t)y : j->bg + 3 * pix; /* render.rs:31-34: one colour per integer pixel */
     po_vec3 bg = ld3(b);
-    po_vec3 total = po_v3(0, 0, 0);
-    for (uint32_t s = 0; s < p->samples; s++) { /* render.rs:36-43; summation order fixed to s ascending (App.B.4) */
+    /* render.rs:36-43 reduces with rayon (no fixed association). The build's summation contract:
+     * chunks of PO_SAMPLE_CHUNK samples, each summed in ascending sample order, then the chunk sums
+     * added in ascending chunk order. */
+    po_vec3 total = po_v3(0, 0, 0), chunk = po_v3(0, 0, 0);
+    for (uint32_t s = 0; s < p->samples; s++) {
         rng_t rng = {p->seed, pix, s, 0, p->jitter_mode};
         double jx = 0.5, jy = 0.5;
         if (p->jitter_mode == PO_JITTER_RNG) { jx = rng_next(&rng); jy = rng_next(&rng); }
@@ -868,7 +873,8 @@ static void render_pixel(const job_t *j, uint32_t x, uint32_t y, po_stats *st) {
         ray_t ray = camera_ray_at(j->cam, (double)x + jx, (double)y + jy);
         st->primary++;
         po_vec3 c = ray_color(j->cx, &ray, bg, 0, &rng, st);
-        total = s == 0 ? c : po_add(total, c); /* Rgb::black() + c == c */
+        chunk = s % PO_SAMPLE_CHUNK == 0 ? c : po_add(chunk, c);
+        if ((s + 1) % PO_SAMPLE_CHUNK == 0 || s + 1 == p->samples) total = s < PO_SAMPLE_CHUNK ? chunk : po_add(total, chunk);
     }
     po_vec3 color = po_divs(total, (double)p->samples); /* render.rs:45 */
     if (j->linear) { double *o = j->linear + 3 * pix; o[0] = color.x; o[1] = color.y; o[2] = color.z; }

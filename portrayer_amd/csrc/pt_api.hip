@@ -27,6 +27,9 @@
 #include "pt_shade.h"
 
 #define PT_BLOCK 256
+#ifndef PT_WORK_BATCH_MAX
+#define PT_WORK_BATCH_MAX 256  // most work items a wavefront takes from the global counter at a time
+#endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument); measured best, profiles/r01/notes.md
 #endif
@@ -65,32 +68,52 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
     if (STATS) memset(&cnt, 0, sizeof cnt);
     PtLane L;
     L.work = PT_IDLE; L.has_ray = false; L.ray_any = false;
-    L.x = L.y = L.sample = L.stage = L.light = L.draw = 0; L.depth = 0;
+    L.x = L.y = L.sample = L.sample_end = L.stage = L.light = L.draw = 0; L.depth = 0;
     L.ray.o = L.ray.d = pt_v3(0.0, 0.0, 0.0);
     PtHit hit;
     hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
     bool exhausted = false;
+    unsigned q_next = 0, q_end = 0, q_seen = 0;  // this wavefront's private batch of work items; highest item index seen handed out
 
     for (;;) {
-        // hand out pixels to idle lanes: one atomic per wavefront
+        // Hand out work items to idle lanes. Each wavefront keeps a private batch [q_next, q_end) of
+        // consecutive items (wave-uniform values) and only goes to the global counter,
+        // with ONE atomicAdd per wavefront, when the batch runs out: a device-scope atomic round trip
+        // stalls the whole wavefront, and with several lanes per pixel some lane finishes almost every
+        // iteration.
         bool need = L.work == PT_IDLE && !exhausted;
         unsigned long long mask = __ballot(need);
         if (mask) {
-            unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(a.work_counter, (unsigned)__popcll(mask));
-            base = __shfl(base, (int)leader);
+            unsigned count = (unsigned)__popcll(mask);
+            unsigned avail = q_end - q_next;
+            unsigned base2 = 0, take = 0;
+            if (count > avail) {
+                // guided batch size: large while plenty of work remains, exactly what is needed near the end
+                unsigned remaining = a.n_work > q_seen ? a.n_work - q_seen : 0u;
+                unsigned b = (remaining / a.work_div) & ~63u;
+                take = b > PT_WORK_BATCH_MAX ? PT_WORK_BATCH_MAX : b;
+                if (take < count - avail) take = count - avail;
+                unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+                if (lane == leader) base2 = atomicAdd(a.work_counter, take);
+                base2 = __shfl(base2, (int)leader);
+                q_seen = base2 + take;
+            }
             if (need) {
-                unsigned w = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                unsigned w = rank < avail ? q_next + rank : base2 + (rank - avail);
                 if (w >= a.n_work) {
                     exhausted = true;
                 } else {
-                    uint32_t x, y;
-                    if (pt_work_to_pixel(a, w, &x, &y)) {
-                        L.work = w; L.x = x; L.y = y; L.sample = 0; L.stage = PT_ST_NEW_SAMPLE;
+                    uint32_t x, y, chunk;
+                    if (pt_work_to_pixel(a, w, &x, &y, &chunk)) {
+                        L.work = w; L.x = x; L.y = y; L.stage = PT_ST_NEW_SAMPLE;
+                        L.sample = chunk * PT_SAMPLE_CHUNK;
+                        L.sample_end = min(a.samples, L.sample + PT_SAMPLE_CHUNK);
                     }
                 }
             }
+            if (count > avail) { q_next = base2 + (count - avail); q_end = base2 + take; }
+            else q_next += count;
         }
         bool active = L.work != PT_IDLE;
         if (!__any(active || !exhausted)) break;
@@ -141,6 +164,12 @@ __global__ void __launch_bounds__(256) pt_copy_kernel(const double2* __restrict_
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// Second pass of a render: chunk sums -> pixels (one thread per pixel slot).
+__global__ void __launch_bounds__(PT_BLOCK) pt_finish_kernel(PtRenderArgs a) {
+    uint32_t p = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (p < a.n_slots) pt_finish_pixel(a, p);
+}
+
 // compact (rank-major, tile-major) -> row-major image
 __global__ void pt_untile_kernel(PtRenderArgs a, uint32_t slots_per_rank, const uint8_t* gathered, uint8_t* rgb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,7 +178,7 @@ __global__ void pt_untile_kernel(PtRenderArgs a, uint32_t slots_per_rank, const 
     PtRenderArgs r = a;
     r.tile_rank = i / slots_per_rank;
     uint32_t w = i % slots_per_rank, x, y;
-    if (!pt_work_to_pixel(r, w, &x, &y)) return;
+    if (!pt_slot_to_pixel(r, w, &x, &y)) return;
     const uint8_t* s = gathered + 3 * (size_t)i;
     uint8_t* d = rgb + 3 * ((size_t)y * a.width + x);
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
@@ -168,7 +197,7 @@ struct pt_context {
     int n_cu = 0;
     std::string err;
     PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh_items, kd, kd_items;
-    PtBuf frames, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
+    PtBuf frames, accum, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
     PtSceneView view;
     bool have_scene = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -232,7 +261,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->frames, &c->bg, &c->rgb, &c->linear, &c->misc};
+                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -518,7 +547,9 @@ static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_par
     a->samples = p->samples; a->seed = p->seed; a->jitter_mode = p->sample_mode;
     a->tile_rank = p->tile_rank; a->tile_ranks = p->tile_ranks;
     bool empty = p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0;  // render.rs:60-65: an inverted slice renders nothing
-    a->n_work = empty ? 0 : pt_slots_per_rank(p);
+    a->n_slots = empty ? 0 : pt_slots_per_rank(p);
+    a->n_chunks = (p->samples + PT_SAMPLE_CHUNK - 1) / PT_SAMPLE_CHUNK;
+    a->n_work = a->n_slots * a->n_chunks;
     return PT_OK;
 }
 
@@ -526,15 +557,22 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     uint32_t grid = 0;
     PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
+    a.work_div = std::max<uint32_t>(grid * (PT_BLOCK / 64) * 8u, 1u);  // batch = remaining work / (8 x resident wavefronts)
     int rc = pt_reserve(c, c->frames, (size_t)a.n_lanes * PT_FRAME_DEPTHS * PT_FRAME_SLOTS * sizeof(double));
     if (rc) return rc;
     if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters)))) return rc;
+    if ((rc = pt_reserve(c, c->accum, (size_t)a.n_work * 3 * sizeof(double)))) return rc;
+    a.accum = (double*)c->accum.p;
     a.frames = (double*)c->frames.p;
     a.work_counter = (unsigned int*)c->misc.p;
     a.counters = (PtCounters*)((char*)c->misc.p + 256);
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters), stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
-    if (a.n_work) PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, true));
+    if (a.n_work) {
+        PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, true));
+        hipLaunchKernelGGL(pt_finish_kernel, dim3((a.n_slots + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, stream, a);
+        PT_HIP(c, hipGetLastError());
+    }
     PT_HIP(c, hipEventRecord(c->ev1, stream));
     return PT_OK;
 }
@@ -657,7 +695,7 @@ extern "C" int pt_tile_slot_pixel(const pt_render_params* p, uint32_t rank, uint
     PtRenderArgs a;
     if (!x || !y || !pt_params_to_args(p, rank, &a)) return PT_ERR_ARGUMENT;
     if (p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0 || slot >= pt_slots_per_rank(p)) return 0;
-    return pt_work_to_pixel(a, slot, x, y) ? 1 : 0;
+    return pt_slot_to_pixel(a, slot, x, y) ? 1 : 0;
 }
 
 extern "C" int pt_untile_host(const pt_render_params* p, const uint8_t* gathered, uint8_t* rgb) {
@@ -669,7 +707,7 @@ extern "C" int pt_untile_host(const pt_render_params* p, const uint8_t* gathered
         a.tile_rank = r;
         for (uint32_t w = 0; w < per; w++) {
             uint32_t x, y;
-            if (!pt_work_to_pixel(a, w, &x, &y)) continue;
+            if (!pt_slot_to_pixel(a, w, &x, &y)) continue;
             const uint8_t* s = gathered + 3 * ((size_t)r * per + w);
             uint8_t* d = rgb + 3 * ((size_t)y * p->width + x);
             d[0] = s[0]; d[1] = s[1]; d[2] = s[2];

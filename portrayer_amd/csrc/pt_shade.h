@@ -28,6 +28,11 @@
 #define PT_SUM_DEPTH (PT_MAX_DEPTH + 1)
 #define PT_FRAME_DEPTHS (PT_MAX_DEPTH + 2)
 #define PT_IDLE 0xFFFFFFFFu
+// Samples of a pixel are summed in chunks of PT_SAMPLE_CHUNK (8): each chunk sequentially (ascending
+// sample index), then the chunk sums sequentially (ascending chunk index). This is the build's
+// summation contract (the reference's rayon reduce has no fixed association, render.rs:36-43); it
+// lets several lanes share one pixel, which keeps all lanes busy when a GPU owns few pixels.
+#define PT_SAMPLE_CHUNK 8
 // A compiler-only fence: stops hipcc from hoisting the loads of one interpreter state above the
 // stores of the previous one (register pressure), costs no instruction.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_STATE_FENCE)
@@ -51,19 +56,23 @@ struct PtRenderArgs {
     uint64_t seed;
     int32_t jitter_mode;
     uint32_t tile_rank, tile_ranks;  // this launch renders 8x8 tiles t with t % tile_ranks == tile_rank
-    uint32_t n_work;                 // pixels slots in this launch (own tiles x 64)
+    uint32_t n_slots;                // pixel slots of this launch (own tiles x 64)
+    uint32_t n_chunks;               // sample chunks per pixel: ceil(samples / PT_SAMPLE_CHUNK)
+    uint32_t n_work;                 // work items of this launch = n_slots x n_chunks
+    double* accum;                   // n_work x 3: per (tile, chunk, pixel) sum of the chunk's samples
     int32_t compact;                 // 1: rgb is tile-major over own tiles; 0: rgb is the full H x W x 3 image
     uint8_t* rgb;
     double* linear;                  // optional, same indexing as rgb
     double* frames;
     uint32_t n_lanes;
     unsigned int* work_counter;
+    uint32_t work_div;               // a wavefront takes (remaining work / work_div) items from work_counter at a time
     PtCounters* counters;
 };
 
 struct PtLane {
     uint32_t work;  // slot index in this launch, PT_IDLE when the lane has no pixel
-    uint32_t x, y, sample, stage, light, draw;
+    uint32_t x, y, sample, sample_end, stage, light, draw;
     int32_t depth;
     PtRay ray;
     bool has_ray, ray_any;
@@ -83,16 +92,23 @@ struct PtFrameRef {
     }
 };
 
-// 8x8 tiles over the slice rectangle, row-major over tiles; work slot w = local tile * 64 + j.
-PT_HD bool pt_work_to_pixel(const PtRenderArgs& a, uint32_t w, uint32_t* x, uint32_t* y) {
+// 8x8 tiles over the slice rectangle, row-major over tiles; pixel slot p = local tile * 64 + j.
+PT_HD bool pt_slot_to_pixel(const PtRenderArgs& a, uint32_t p, uint32_t* x, uint32_t* y) {
     uint32_t rw = a.x1 - a.x0 + 1;
     uint32_t tiles_x = (rw + 7) / 8;
-    uint32_t tile = (w >> 6) * a.tile_ranks + a.tile_rank;
-    uint32_t j = w & 63;
+    uint32_t tile = (p >> 6) * a.tile_ranks + a.tile_rank;
+    uint32_t j = p & 63;
     uint32_t px = a.x0 + (tile % tiles_x) * 8 + (j & 7);
     uint32_t py = a.y0 + (tile / tiles_x) * 8 + (j >> 3);
     *x = px; *y = py;
     return px <= a.x1 && py <= a.y1;
+}
+// Work item w = ((local tile * n_chunks) + chunk) * 64 + j: the 64 lanes of a wavefront start on one
+// 8x8 tile and one sample chunk.
+PT_HD bool pt_work_to_pixel(const PtRenderArgs& a, uint32_t w, uint32_t* x, uint32_t* y, uint32_t* chunk) {
+    uint32_t g = w >> 6;
+    *chunk = g % a.n_chunks;
+    return pt_slot_to_pixel(a, ((g / a.n_chunks) << 6) | (w & 63), x, y);
 }
 
 PT_HD PtVec3 pt_background(const PtRenderArgs& a, uint32_t x, uint32_t y) {  // render.rs:31-34
@@ -146,9 +162,15 @@ PT_HD bool pt_refracted_direction(PtVec3 ray_dir, PtVec3 normal, double eta, PtV
     return true;
 }
 
-PT_HD void pt_finish_pixel(const PtRenderArgs& a, const PtLane& L, PtVec3 sum) {  // render.rs:45-50, :143-147
+// One pixel's chunk sums -> mean, gamma, clamp, u8 (render.rs:45-50, :143-147). p = pixel slot.
+PT_HD void pt_finish_pixel(const PtRenderArgs& a, uint32_t p) {
+    uint32_t x, y;
+    if (!pt_slot_to_pixel(a, p, &x, &y)) return;
+    const double* acc = a.accum + 3 * ((size_t)(p >> 6) * a.n_chunks * 64 + (p & 63));
+    PtVec3 sum = pt_v3(acc[0], acc[1], acc[2]);
+    for (uint32_t k = 1; k < a.n_chunks; k++) sum = sum + pt_v3(acc[192 * (size_t)k], acc[192 * (size_t)k + 1], acc[192 * (size_t)k + 2]);
     PtVec3 color = sum / (double)a.samples;
-    size_t idx = a.compact ? (size_t)L.work : (size_t)L.y * a.width + L.x;
+    size_t idx = a.compact ? (size_t)p : (size_t)y * a.width + x;
     if (a.linear) { double* o = a.linear + 3 * idx; o[0] = color.x; o[1] = color.y; o[2] = color.z; }
     const double g = 1.0 / PT_GAMMA;
     double ch[3] = {pt_pow(color.x, g), pt_pow(color.y, g), pt_pow(color.z, g)};
@@ -193,8 +215,8 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         if (returning) {
             // `value` = Ray::color() of the ray cast at depth L.depth
             returning = false;
-            if (L.depth == 0) {  // render.rs:36-43: samples summed in ascending order
-                if (L.sample != 0) value = fr.load3(PT_SUM_DEPTH, 0) + value;
+            if (L.depth == 0) {  // render.rs:36-43: the chunk's samples summed in ascending order
+                if (L.sample % PT_SAMPLE_CHUNK != 0) value = fr.load3(PT_SUM_DEPTH, 0) + value;
                 fr.store3(PT_SUM_DEPTH, 0, value);
                 L.sample++;
                 L.stage = PT_ST_NEW_SAMPLE;
@@ -259,8 +281,10 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         switch (L.stage) {
         case PT_ST_NEW_SAMPLE: {
             PT_FENCE;
-            if (L.sample >= a.samples) {
-                pt_finish_pixel(a, L, fr.load3(PT_SUM_DEPTH, 0));
+            if (L.sample >= L.sample_end) {  // chunk done: hand its sum to the finishing pass
+                PtVec3 sum = fr.load3(PT_SUM_DEPTH, 0);
+                double* o = a.accum + 3 * (size_t)L.work;
+                o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
                 L.work = PT_IDLE;
                 return;
             }

@@ -69,14 +69,16 @@ def test_example_matches_oracle(oracle, host, H, name, size, mode):
     r.close()
 
 
-def test_samples_and_jitter_match_oracle(oracle, host, H):
-    """SAMPLES > 1 with the counter-based jitter: same sample positions, same summation order."""
+@pytest.mark.parametrize("samples", [8, 20, 64])
+def test_samples_and_jitter_match_oracle(oracle, host, H, samples):
+    """SAMPLES > 1 with the counter-based jitter: same sample positions, same summation order (chunks of
+    8 samples, several lanes per pixel: 20 = two full chunks and a partial one)."""
     sc = host.Scene.example("entering-the-mirror-dimension", assets=ASSETS)
     w, h = 192, 108
     r = host.Renderer(sc, H.TRAVERSE_FLAT)
-    rgb, linear, _ = r.render(sc.camera, w, h, default_background(w, h), samples=16, seed=7, sample_mode=H.SAMPLE_RNG)
+    rgb, linear, _ = r.render(sc.camera, w, h, default_background(w, h), samples=samples, seed=7, sample_mode=H.SAMPLE_RNG)
     cam = EXAMPLES["entering-the-mirror-dimension"]()[1]
-    ref = oracle.render(oracle_from(oracle, sc), cam, w, h, samples=16, seed=7, jitter=oracle.JITTER_RNG, mode=oracle.MODE_FLAT)
+    ref = oracle.render(oracle_from(oracle, sc), cam, w, h, samples=samples, seed=7, jitter=oracle.JITTER_RNG, mode=oracle.MODE_FLAT)
     assert np.array_equal(rgb, ref.rgb)
     assert ulp_diff(linear, ref.linear).max() <= 256
 
