@@ -51,6 +51,18 @@ def algorithmic_bytes(st, n_lights, pixels, traversal):
             + st["hits"] * (168 + 80 + 120 * n_lights) + 27 * pixels)
 
 
+def measured_traffic(workload, traversal, n_gpus):
+    """HBM bytes per render-kernel launch from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, KB -> bytes; collected by profiles/run_profile.sh on this
+    command). None when no profile of this exact workload is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        return t.get(f"{workload}/{traversal}/gpus{n_gpus}", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,7 +236,8 @@ def main():
                        "rays_per_frame": rays_frame,
                        "rays": {k: total[k] for k in ("primary", "shadow", "reflect", "refract")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "pt_render_kernel", "kernel_ms": mean_kernel_s * 1e3,
+                         "traffic": measured_traffic(args.workload, args.traversal, world) if (w, h, s) == WORKLOADS[args.workload][2:] and args.share == 1 else None,
+                         "kernel": "pt_render_kernel", "kernel_ms": mean_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": mine_bytes,
                          "per_ray": {"inner_nodes": total["n_inner"] / rays_frame, "primitive_tests": total["n_analytic"] / rays_frame,
                                      "triangle_tests": total["n_tri"] / rays_frame}},
