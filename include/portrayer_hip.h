@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 /* enum Primitive, src/primitive.rs:67-81 */
 enum { PT_PRIM_SPHERE = 0, PT_PRIM_TRIANGLE = 1, PT_PRIM_MESH = 2, PT_PRIM_KDMESH = 3, PT_PRIM_PLANE = 4, PT_PRIM_CUBE = 5, PT_PRIM_CYLINDER = 6, PT_PRIM_CONE = 7 };
@@ -47,7 +47,8 @@ enum {
     PT_ERR_DEVICE = -2,     /* HIP runtime error (text in pt_last_error)                             */
     PT_ERR_NO_SCENE = -3,   /* pt_render before pt_scene_upload                                      */
     PT_ERR_SLICE = -4,      /* slice corner outside the image: ImageSliceMut::new panics, render.rs:79-90 */
-    PT_ERR_SCENE = -5,      /* inconsistent scene (mesh without vertices, mesh.rs:71; smooth shading without normals, mesh.rs:135-138) */
+    PT_ERR_SCENE = -5,      /* inconsistent scene (mesh without vertices, mesh.rs:71; smooth shading without normals, mesh.rs:135-138;
+                               a textured material on a primitive without texture coordinates, material.rs:133,141) */
     PT_ERR_TRAVERSAL = -6   /* a lane ran out of traversal stack (never expected; results invalid)    */
 };
 
@@ -85,6 +86,20 @@ typedef struct {
     uint32_t n_lights;
     const double *lights;            /* n_lights x 15                                                     */
     double ambient[3];               /* Scene::ambient, src/scene.rs:17                                   */
+    /* Image textures and normal maps, src/texture.rs (ABI 2). All optional: leave NULL / 0 for scenes
+     * without textured materials. Texels are the RGB8 pixels as the image decoder returns them
+     * (RgbImageBuffer, texture.rs:74-76); sRGB -> linear (texture.rs:162-168) happens at sampling. */
+    const double *mesh_texcoords;       /* total vertices x 2 (MeshData::tex_coords, mesh.rs:30), or NULL  */
+    const uint8_t *mesh_has_texcoords;  /* n_meshes, or NULL                                               */
+    const double *tri_texcoords;        /* n_triangles x 6 (Triangle::tex_coords, triangle.rs:18), or NULL */
+    const uint8_t *tri_has_texcoords;   /* n_triangles, or NULL                                            */
+    const int32_t *material_texture;    /* n_materials: texture index or -1 (Material::texture, material.rs:75) */
+    const int32_t *material_normal_map; /* n_materials: texture index or -1 (Material::normals, material.rs:85) */
+    const double *material_uv_trans;    /* n_materials x 9 row-major Mat3 (material.rs:83); NULL = identity  */
+    uint32_t n_textures;
+    const uint32_t *texture_size;       /* n_textures x 2: width, height                                   */
+    const uint64_t *texture_offset;     /* n_textures: byte offset of texel (0,0) in texture_rgb           */
+    const uint8_t *texture_rgb;         /* all texels, row-major RGB8                                      */
 } pt_scene;
 
 /* The scene k-d tree the host built (KDTreeScene::from, src/kdtree/kdscene.rs:19-43), linearised;

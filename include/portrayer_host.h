@@ -45,6 +45,11 @@ typedef struct {
     uint32_t n_materials; const double *materials; /* x 10, layout of pt_scene.materials                  */
     uint32_t n_lights; const double *lights;       /* x 15, layout of pt_scene.lights                     */
     double ambient[3];
+    /* textures (src/texture.rs), same layout as the pt_scene fields of the same names; optional */
+    const double *mesh_texcoords; const uint8_t *mesh_has_texcoords;
+    const double *tri_texcoords; const uint8_t *tri_has_texcoords;
+    const int32_t *material_texture, *material_normal_map; const double *material_uv_trans;
+    uint32_t n_textures; const uint32_t *texture_size; const uint64_t *texture_offset; const uint8_t *texture_rgb;
 } ph_scene_desc;
 
 const char *ph_last_error(void);

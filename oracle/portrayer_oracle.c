@@ -17,7 +17,19 @@
 #define PO_SAMPLE_CHUNK 8
 
 typedef struct { po_vec3 o, d; } ray_t;          /* ray.rs:102-108 */
-typedef struct { double t; po_vec3 p, n; } hit_t; /* ray.rs:10-36 (tex_coord / TBN are "next") */
+typedef struct { double m[3][3]; } po_mat3;
+/* ray.rs:10-36: tex_coord / normal_map_transform are Option<..>: has_uv / has_tbn */
+typedef struct { double t; po_vec3 p, n; int has_uv, has_tbn; double u, v; po_mat3 tbn; } hit_t;
+
+static inline po_vec3 mat3_mul(const po_mat3 *m, po_vec3 v) { /* vek Mat3 * Vec3, row dot products left to right */
+    return po_v3((m->m[0][0] * v.x + m->m[0][1] * v.y) + m->m[0][2] * v.z,
+                 (m->m[1][0] * v.x + m->m[1][1] * v.y) + m->m[1][2] * v.z,
+                 (m->m[2][0] * v.x + m->m[2][1] * v.y) + m->m[2][2] * v.z);
+}
+static inline po_mat3 mat3_from_cols(po_vec3 c0, po_vec3 c1, po_vec3 c2) { /* Mat3::from_col_arrays */
+    po_mat3 m = {{{c0.x, c1.x, c2.x}, {c0.y, c1.y, c2.y}, {c0.z, c1.z, c2.z}}};
+    return m;
+}
 
 /* ---------------------------------------------------------------------------------------------
  * ray.rs
@@ -47,6 +59,7 @@ static inline int iplane_hit(const iplane_t *pl, const ray_t *ray, const po_rang
     hit->t = t;
     hit->p = ray_at(ray, t);
     hit->n = pl->normal;
+    hit->has_uv = hit->has_tbn = 0;
     return 1;
 }
 
@@ -64,17 +77,39 @@ static int cube_hit(const ray_t *ray, const po_range *init, hit_t *out) { /* cub
         {{0, 1, 0}, {0, 0.5, 0}}, {{0, -1, 0}, {0, -0.5, 0}},
         {{0, 0, 1}, {0, 0, 0.5}}, {{0, 0, -1}, {0, 0, -0.5}},
     };
+    /* cube.rs:46-66: (uv axis direction, uv offset in the 4x3 cube map) per face */
+    static const double uv_axis[6][2] = {{-1, 1}, {1, 1}, {1, -1}, {1, 1}, {1, 1}, {-1, 1}};
+    static const double uv_off[6][2] = {{1.0 / 2.0, 1.0 / 3.0}, {0.0, 1.0 / 3.0}, {1.0 / 4.0, 0.0}, {1.0 / 4.0, 2.0 / 3.0}, {1.0 / 4.0, 1.0 / 3.0}, {3.0 / 4.0, 1.0 / 3.0}};
     po_range range = *init;
-    int found = 0;
+    int found = 0, face = 0;
     for (int f = 0; f < 6; f++) {
         hit_t h;
         if (iplane_hit(&faces[f], ray, &range, &h) && cube_contains(h.p)) {
             range.end = h.t;
             *out = h;
+            face = f;
             found = 1;
         }
     }
-    return found;
+    if (!found) return 0;
+    /* cube.rs:84-139: computed once for the winning face */
+    po_vec3 p = out->p, fn = faces[face].normal;
+    double fu, fv;
+    if (fn.x != 0.0) { fu = p.z; fv = p.y; } else if (fn.y != 0.0) { fu = p.x; fv = p.z; } else { fu = p.x; fv = p.y; }
+    double nu = fu * uv_axis[face][0] + 0.5, nv = 0.5 - fv * uv_axis[face][1];
+    out->has_uv = 1;
+    out->u = nu / 4.0 + uv_off[face][0];
+    out->v = nv / 3.0 + uv_off[face][1];
+    po_vec3 to_top = po_normalized(po_sub(po_v3(0.0, 1.0, 0.0), p));
+    if (fabs(to_top.x) < PO_EPSILON && fabs(to_top.z) < PO_EPSILON) {
+        out->tbn = mat3_from_cols(po_v3(1, 0, 0), fn, fn.y > 0.0 ? po_v3(0, 0, 1) : po_v3(0, 0, -1));
+    } else {
+        po_vec3 ht = po_cross(to_top, fn);
+        po_vec3 vt = po_cross(fn, ht);
+        out->tbn = mat3_from_cols(ht, fn, vt);
+    }
+    out->has_tbn = 1;
+    return 1;
 }
 
 static int plane_hit(const ray_t *ray, const po_range *range, hit_t *out) { /* plane.rs:25-53 */
@@ -83,6 +118,8 @@ static int plane_hit(const ray_t *ray, const po_range *range, hit_t *out) { /* p
     if (!iplane_hit(&pl, ray, range, &h)) return 0;
     double radius = 0.5 + PO_EPSILON;
     if (!(-radius <= h.p.x && h.p.x <= radius && -radius <= h.p.z && h.p.z <= radius)) return 0;
+    h.has_uv = 1; h.u = h.p.x + 0.5; h.v = h.p.z + 0.5; /* plane.rs:40-43 */
+    h.has_tbn = 1; h.tbn = mat3_from_cols(po_v3(1, 0, 0), po_v3(0, 1, 0), po_v3(0, 0, 1)); /* plane.rs:46 */
     *out = h;
     return 1;
 }
@@ -96,6 +133,21 @@ static int sphere_hit(const ray_t *ray, const po_range *range, hit_t *out) { /* 
     out->t = t;
     out->p = ray_at(ray, t);
     out->n = out->p;
+    /* sphere.rs:53-96 */
+    const double PI = 3.14159265358979323846;
+    po_vec3 p = out->p, normal = out->p;
+    out->has_uv = 1;
+    out->u = (PI + atan2(-p.z, p.x)) / (2.0 * PI);
+    out->v = acos(p.y) / PI;
+    po_vec3 to_top = po_normalized(po_sub(po_v3(0.0, 1.0, 0.0), p));
+    if (fabs(to_top.x) < PO_EPSILON && fabs(to_top.z) < PO_EPSILON) {
+        out->tbn = mat3_from_cols(po_v3(1, 0, 0), normal, normal.y > 0.0 ? po_v3(0, 0, 1) : po_v3(0, 0, -1));
+    } else {
+        po_vec3 ht = po_cross(to_top, normal);
+        po_vec3 vt = po_cross(normal, ht);
+        out->tbn = mat3_from_cols(ht, normal, vt);
+    }
+    out->has_tbn = 1;
     return 1;
 }
 
@@ -108,7 +160,7 @@ static int cylinder_body(const ray_t *ray, const po_range *range, hit_t *out) { 
     if (!po_first_root_in_range(a, b, c, range, &t)) return 0;
     po_vec3 p = ray_at(ray, t);
     if (p.y > 0.5 || p.y < -0.5) return 0;
-    out->t = t; out->p = p; out->n = po_v3(p.x, 0.0, p.z);
+    out->t = t; out->p = p; out->n = po_v3(p.x, 0.0, p.z); out->has_uv = out->has_tbn = 0;
     return 1;
 }
 static int cylinder_cap(double height, const ray_t *ray, const po_range *range, hit_t *out) { /* cylinder.rs:80-119 */
@@ -116,7 +168,7 @@ static int cylinder_cap(double height, const ray_t *ray, const po_range *range, 
     if (!po_contains(range, t)) return 0;
     po_vec3 p = ray_at(ray, t);
     if ((p.x * p.x + p.z * p.z) > 0.5 * 0.5) return 0;
-    out->t = t; out->p = p; out->n = po_v3(0.0, height / fabs(height), 0.0);
+    out->t = t; out->p = p; out->n = po_v3(0.0, height / fabs(height), 0.0); out->has_uv = out->has_tbn = 0;
     return 1;
 }
 static int cylinder_hit(const ray_t *ray, const po_range *init, hit_t *out) { /* cylinder.rs:121-154 */
@@ -146,7 +198,7 @@ static int cone_body(const ray_t *ray, const po_range *range, hit_t *out) { /* c
     po_vec3 opposite = po_v3(-p.x, p.y, -p.z);
     po_vec3 across = po_sub(opposite, p);
     po_vec3 tangent2 = po_cross(tangent1, across);
-    out->t = t; out->p = p; out->n = po_cross(tangent1, tangent2);
+    out->t = t; out->p = p; out->n = po_cross(tangent1, tangent2); out->has_uv = out->has_tbn = 0;
     return 1;
 }
 static int cone_cap(const ray_t *ray, const po_range *range, hit_t *out) { /* cone.rs:117-157 */
@@ -155,7 +207,7 @@ static int cone_cap(const ray_t *ray, const po_range *range, hit_t *out) { /* co
     if (!po_contains(range, t)) return 0;
     po_vec3 p = ray_at(ray, t);
     if ((p.x * p.x + p.z * p.z) > 0.5 * 0.5) return 0;
-    out->t = t; out->p = p; out->n = po_v3(0.0, -1.0, 0.0);
+    out->t = t; out->p = p; out->n = po_v3(0.0, -1.0, 0.0); out->has_uv = out->has_tbn = 0;
     return 1;
 }
 static int cone_hit(const ray_t *ray, const po_range *init, hit_t *out) { /* cone.rs:159-187 */
@@ -167,7 +219,7 @@ static int cone_hit(const ray_t *ray, const po_range *init, hit_t *out) { /* con
     return found;
 }
 
-typedef struct { po_vec3 a, b, c; int has_n; po_vec3 na, nb, nc; } tri_t; /* triangle.rs:8-19 */
+typedef struct { po_vec3 a, b, c; int has_n; po_vec3 na, nb, nc; int has_uv; double uv[6]; } tri_t; /* triangle.rs:8-19 */
 
 static int triangle_hit(const tri_t *tr, const ray_t *ray, const po_range *range, hit_t *out) { /* triangle.rs:38-147 */
     po_vec3 ab = po_sub(tr->a, tr->b), ac = po_sub(tr->a, tr->c), ao = po_sub(tr->a, ray->o);
@@ -202,6 +254,22 @@ static int triangle_hit(const tri_t *tr, const ray_t *ray, const po_range *range
     out->t = t;
     out->p = ray_at(ray, t);
     out->n = normal;
+    out->has_uv = out->has_tbn = 0;
+    if (tr->has_uv) { /* triangle.rs:90-138 */
+        double ua = tr->uv[0], va = tr->uv[1], ub = tr->uv[2], vb = tr->uv[3], uc = tr->uv[4], vc = tr->uv[5];
+        double alpha = 1.0 - beta - gamma;
+        double uu = (ua * alpha + ub * beta) + uc * gamma, vv = (va * alpha + vb * beta) + vc * gamma;
+        out->has_uv = 1; out->u = uu; out->v = 1.0 - vv;
+        po_vec3 edge1 = po_sub(tr->b, tr->a), edge2 = po_sub(tr->c, tr->a);
+        double du1 = ub - ua, dv1 = vb - va, du2 = uc - ua, dv2 = vc - va;
+        po_vec3 tangent = po_v3(dv2 * edge1.x - dv1 * edge2.x, dv2 * edge1.y - dv1 * edge2.y, dv2 * edge1.z - dv1 * edge2.z);
+        po_vec3 bitangent = po_v3(-du2 * edge1.x + du1 * edge2.x, -du2 * edge1.y + du1 * edge2.y, -du2 * edge1.z + du1 * edge2.z);
+        double coeff = du1 * dv2 - du2 * dv1;
+        tangent = po_normalized(po_divs(tangent, coeff));
+        bitangent = po_normalized(po_divs(bitangent, coeff));
+        out->tbn = mat3_from_cols(tangent, po_normalized(normal), bitangent);
+        out->has_tbn = 1;
+    }
     return 1;
 }
 
@@ -375,8 +443,8 @@ static int kd_cast(const kdnode_t *node, const ray_t *ray, po_range *range, doub
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     uint32_t n_verts, n_tris;
-    const double *pos, *nrm; const uint32_t *idx;
-    int has_normals;
+    const double *pos, *nrm, *uv; const uint32_t *idx;
+    int has_normals, has_uv;
     bbox_t bounds;              /* mesh.rs:69-75 */
     kdnode_t *kd[2];            /* kdmesh.rs:37-58, per Shading (0 flat, 1 smooth) */
     bbox_t kd_bounds[2];        /* root bounds incl. invtrans (kdmesh.rs:26-30) */
@@ -390,6 +458,8 @@ static tri_t mesh_triangle(const mesh_t *m, uint32_t i, int smooth) { /* mesh.rs
     t.a = ld3(m->pos + 3 * a); t.b = ld3(m->pos + 3 * b); t.c = ld3(m->pos + 3 * c);
     t.has_n = smooth;
     if (smooth) { t.na = ld3(m->nrm + 3 * a); t.nb = ld3(m->nrm + 3 * b); t.nc = ld3(m->nrm + 3 * c); }
+    t.has_uv = m->has_uv; /* mesh.rs:106-110 */
+    if (m->has_uv) { t.uv[0] = m->uv[2 * a]; t.uv[1] = m->uv[2 * a + 1]; t.uv[2] = m->uv[2 * b]; t.uv[3] = m->uv[2 * b + 1]; t.uv[4] = m->uv[2 * c]; t.uv[5] = m->uv[2 * c + 1]; }
     return t;
 }
 
@@ -472,6 +542,8 @@ static int prim_hit(const ctx_t *cx, int type, int data, int flags, const ray_t 
         t.a = ld3(v); t.b = ld3(v + 3); t.c = ld3(v + 6);
         t.has_n = cx->sc->tri_has_normals && cx->sc->tri_has_normals[data];
         if (t.has_n) { const double *n = cx->sc->tri_normals + 9 * (size_t)data; t.na = ld3(n); t.nb = ld3(n + 3); t.nc = ld3(n + 6); }
+        t.has_uv = cx->sc->tri_has_texcoords && cx->sc->tri_texcoords && cx->sc->tri_has_texcoords[data];
+        if (t.has_uv) memcpy(t.uv, cx->sc->tri_texcoords + 6 * (size_t)data, sizeof t.uv);
         st->n_tri++;
         return triangle_hit(&t, ray, range, out);
     }
@@ -642,6 +714,8 @@ static int ctx_init(ctx_t *cx, const po_scene *sc, int mode, int kd_depth, int k
         m->nrm = sc->mesh_normals ? sc->mesh_normals + 3 * sc->mesh_vert_off[i] : NULL;
         m->idx = sc->mesh_indices + 3 * sc->mesh_tri_off[i];
         m->has_normals = sc->mesh_has_normals ? sc->mesh_has_normals[i] : 0;
+        m->has_uv = sc->mesh_has_texcoords && sc->mesh_texcoords && sc->mesh_has_texcoords[i];
+        m->uv = m->has_uv ? sc->mesh_texcoords + 2 * sc->mesh_vert_off[i] : NULL;
         if (m->n_verts == 0) return -3; /* mesh.rs:71 assert */
         po_vec3 mn = ld3(m->pos), mx = mn; /* mesh.rs:72-75 */
         for (uint32_t v = 1; v < m->n_verts; v++) { po_vec3 p = ld3(m->pos + 3 * v); mn = po_vmin(mn, p); mx = po_vmax(mx, p); }
@@ -704,8 +778,21 @@ static inline double powi5(double x) { /* f64::powi(5) = llvm.powi: x * ((x*x)*(
     return x * x4;
 }
 
+/* texture.rs:96-141 RgbImageBuffer::at: nearest texel, wrap-around; channels as f64 / 255 */
+static po_vec3 texel_at(const po_scene *sc, int32_t tex, double u, double v) {
+    int64_t width = sc->texture_size[2 * tex], height = sc->texture_size[2 * tex + 1];
+    double fx = u * (double)(width - 1), fy = v * (double)(height - 1);
+    /* Rust `as i64`: truncation toward zero, saturating, NaN -> 0 */
+    int64_t x = fx != fx ? 0 : (fx >= 9.2233720368547758e18 ? INT64_MAX : (fx <= -9.2233720368547758e18 ? INT64_MIN : (int64_t)fx));
+    int64_t y = fy != fy ? 0 : (fy >= 9.2233720368547758e18 ? INT64_MAX : (fy <= -9.2233720368547758e18 ? INT64_MIN : (int64_t)fy));
+    x %= width; if (x < 0) x += width; /* rem_euclid, texture.rs:99-112 */
+    y %= height; if (y < 0) y += height;
+    const uint8_t *px = sc->texture_rgb + sc->texture_offset[tex] + 3 * ((size_t)y * (size_t)width + (size_t)x);
+    return po_v3((double)px[0] / 255.0, (double)px[1] / 255.0, (double)px[2] / 255.0);
+}
+
 static po_vec3 hit_color(const ctx_t *cx, int32_t mat_id, po_vec3 bg, po_vec3 ray_dir, po_vec3 hit_point, po_vec3 normal_raw,
-                         uint32_t depth, rng_t *rng, po_stats *st) { /* material.rs:91-320 */
+                         const hit_t *hit, uint32_t depth, rng_t *rng, po_stats *st) { /* material.rs:91-320 */
     if (depth > 10) return bg; /* material.rs:12, :102-104 */
     st->hits++;
     const po_scene *sc = cx->sc;
@@ -714,7 +801,31 @@ static po_vec3 hit_color(const ctx_t *cx, int32_t mat_id, po_vec3 bg, po_vec3 ra
     double shininess = m[6], reflectivity = m[7], glossy = m[8], ior = m[9];
 
     po_vec3 view = po_neg(ray_dir);
-    po_vec3 normal = po_normalized(normal_raw); /* material.rs:123-125 (no normal map) */
+    int32_t tex = sc->material_texture ? sc->material_texture[mat_id] : -1;
+    int32_t nmap = sc->material_normal_map ? sc->material_normal_map[mat_id] : -1;
+    double tu = hit->u, tv = hit->v;
+    if (hit->has_uv && sc->material_uv_trans) { /* material.rs:113-117: uv_trans * (u, v, 1), w dropped */
+        const double *t9 = sc->material_uv_trans + 9 * (size_t)mat_id;
+        double nu = (t9[0] * hit->u + t9[1] * hit->v) + t9[2] * 1.0;
+        double nv = (t9[3] * hit->u + t9[4] * hit->v) + t9[5] * 1.0;
+        tu = nu; tv = nv;
+    }
+    po_vec3 normal;
+    if (nmap < 0) {
+        normal = po_normalized(normal_raw); /* material.rs:123-125 */
+    } else { /* material.rs:126-136 + texture.rs:192-221; quirk Q12: the TBN is the primitive's model-space one */
+        if (!hit->has_uv || !hit->has_tbn) { st->kd_plane_miss += 1u << 20; return bg; } /* the reference panics */
+        po_vec3 tn = texel_at(sc, nmap, tu, tv);
+        po_vec3 norm = po_v3(2.0 * tn.x - 1.0, 2.0 * tn.y - 1.0, -(2.0 * tn.z - 1.0));
+        po_mat3 to_rh = {{{1, 0, 0}, {0, 0, -1}, {0, -1, 0}}};
+        po_vec3 tex_norm = mat3_mul(&to_rh, norm);
+        normal = mat3_mul(&hit->tbn, po_normalized(tex_norm));
+    }
+    if (tex >= 0) { /* material.rs:138-144, texture.rs:162-168: sRGB -> linear with powf(2.2) */
+        if (!hit->has_uv) { st->kd_plane_miss += 1u << 20; return bg; } /* the reference panics */
+        po_vec3 c = texel_at(sc, tex, tu, tv);
+        kd = po_v3(pow(c.x, PO_GAMMA), pow(c.y, PO_GAMMA), pow(c.z, PO_GAMMA));
+    }
     po_vec3 color = po_mul(po_v3(sc->ambient[0], sc->ambient[1], sc->ambient[2]), kd); /* :148 */
     for (uint32_t li = 0; li < sc->n_lights; li++) { /* :149-211 */
         const double *L = sc->lights + 15 * (size_t)li;
@@ -795,7 +906,7 @@ static po_vec3 ray_color(const ctx_t *cx, const ray_t *ray, po_vec3 bg, uint32_t
     po_range range = {PO_EPSILON, INFINITY};
     hit_t h; int32_t mat, id;
     if (scene_cast(cx, ray, &range, &h, &mat, &id, st))
-        return hit_color(cx, mat, bg, ray->d, h.p, h.n, depth, rng, st);
+        return hit_color(cx, mat, bg, ray->d, h.p, h.n, &h, depth, rng, st);
     return bg;
 }
 

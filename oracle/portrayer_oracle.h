@@ -58,6 +58,18 @@ typedef struct {
     uint32_t n_lights;
     const double *lights;            /* x 15 */
     double ambient[3];
+    /* texture.rs: image textures / normal maps (all optional: NULL / 0 when the scene has none) */
+    const double *mesh_texcoords;    /* total_verts x 2 (mesh.rs:30) */
+    const uint8_t *mesh_has_texcoords; /* n_meshes */
+    const double *tri_texcoords;     /* n_triangles x 6 (triangle.rs:18) */
+    const uint8_t *tri_has_texcoords; /* n_triangles */
+    const int32_t *material_texture;    /* n_materials: index into textures, -1 = none (material.rs:75) */
+    const int32_t *material_normal_map; /* n_materials: index into textures, -1 = none (material.rs:85) */
+    const double *material_uv_trans;    /* n_materials x 9, row-major Mat3 (material.rs:83) */
+    uint32_t n_textures;
+    const uint32_t *texture_size;    /* n_textures x 2: width, height */
+    const uint64_t *texture_offset;  /* n_textures: byte offset of the first texel in texture_rgb */
+    const uint8_t *texture_rgb;      /* RGB8 texels, row-major (RgbImageBuffer, texture.rs:74-76) */
 } po_scene;
 
 typedef struct { double eye[3], center[3], up[3], fovy_radians; } po_camera_settings; /* camera.rs:5-14 */

@@ -37,6 +37,9 @@ class PtScene(C.Structure):
         ("n_materials", C.c_uint32), ("materials", _dp),
         ("n_lights", C.c_uint32), ("lights", _dp),
         ("ambient", C.c_double * 3),
+        ("mesh_texcoords", _dp), ("mesh_has_texcoords", _u8p), ("tri_texcoords", _dp), ("tri_has_texcoords", _u8p),
+        ("material_texture", _ip), ("material_normal_map", _ip), ("material_uv_trans", _dp),
+        ("n_textures", C.c_uint32), ("texture_size", _up), ("texture_offset", _u64p), ("texture_rgb", _u8p),
     ]
 
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCount
         if (s[i]) atomicAdd(d + i, s[i]);
 }
 
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool TEX>
 __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRenderArgs a) {
     extern __shared__ uint32_t pt_lds[];
     PtStack stk;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
         }
         bool active = L.work != PT_IDLE;
         if (!__any(active || !exhausted)) break;
-        if (active) pt_lane_advance<STATS>(a, L, hit, fr, &cnt);
+        if (active) pt_lane_advance<STATS, TEX>(a, L, hit, fr, &cnt);
         if (L.work != PT_IDLE && L.has_ray) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
     }
     if (STATS) pt_flush_counters(a.counters, cnt);
@@ -197,6 +197,7 @@ struct pt_context {
     int n_cu = 0;
     std::string err;
     PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh_items, kd, kd_items;
+    PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv;
     PtBuf frames, accum, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
     PtSceneView view;
     bool have_scene = false;
@@ -261,7 +262,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc};
+                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -469,6 +470,67 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
     if ((rc = pt_upload(c, c->materials, mats)) || (rc = pt_upload(c, c->lights, lights))) return rc;
 
+    // ---- textures / normal maps (texture.rs)
+    bool textured = false;
+    for (uint32_t m = 0; m < s->n_materials; m++)
+        if ((s->material_texture && s->material_texture[m] >= 0) || (s->material_normal_map && s->material_normal_map[m] >= 0)) textured = true;
+    std::vector<int32_t> mat_maps;
+    std::vector<double> uv_trans, srgb_lut, tri_uv;
+    std::vector<PtTexInfo> texinfo;
+    std::vector<uint8_t> tex_rgb;
+    if (textured) {
+        if (s->n_textures == 0 || !s->texture_size || !s->texture_offset || !s->texture_rgb) return pt_fail(c, PT_ERR_ARGUMENT, "textured material without texture data");
+        size_t tex_bytes = 0;
+        texinfo.resize(s->n_textures);
+        for (uint32_t t = 0; t < s->n_textures; t++) {
+            texinfo[t].offset = s->texture_offset[t]; texinfo[t].width = s->texture_size[2 * t]; texinfo[t].height = s->texture_size[2 * t + 1];
+            if (texinfo[t].width == 0 || texinfo[t].height == 0) return pt_fail(c, PT_ERR_ARGUMENT, "empty texture");
+            tex_bytes = std::max(tex_bytes, (size_t)texinfo[t].offset + 3 * (size_t)texinfo[t].width * texinfo[t].height);
+        }
+        tex_rgb.assign(s->texture_rgb, s->texture_rgb + tex_bytes);
+        mat_maps.resize(2 * (size_t)s->n_materials);
+        uv_trans.resize(9 * (size_t)s->n_materials);
+        for (uint32_t m = 0; m < s->n_materials; m++) {
+            int32_t a = s->material_texture ? s->material_texture[m] : -1, b = s->material_normal_map ? s->material_normal_map[m] : -1;
+            if (a >= (int32_t)s->n_textures || b >= (int32_t)s->n_textures) return pt_fail(c, PT_ERR_ARGUMENT, "texture index out of range");
+            mat_maps[2 * m] = a < 0 ? -1 : a; mat_maps[2 * m + 1] = b < 0 ? -1 : b;
+            for (int k = 0; k < 9; k++) uv_trans[9 * (size_t)m + k] = s->material_uv_trans ? s->material_uv_trans[9 * (size_t)m + k] : (k % 4 == 0 ? 1.0 : 0.0);
+        }
+        srgb_lut.resize(256);
+        for (int k = 0; k < 256; k++) srgb_lut[k] = std::pow((double)k / 255.0, PT_GAMMA);  // texture.rs:167: c.powf(GAMMA), c = byte / 255
+        tri_uv.assign(total_tris * 6, 0.0);
+        std::vector<uint8_t> tri_has_uv(total_tris, 0);
+        for (uint32_t m = 0; m < s->n_meshes; m++) {
+            if (!(s->mesh_texcoords && s->mesh_has_texcoords && s->mesh_has_texcoords[m])) continue;
+            uint64_t v0 = s->mesh_vert_off[m];
+            for (uint64_t t = s->mesh_tri_off[m]; t < s->mesh_tri_off[m + 1]; t++) {
+                for (int corner = 0; corner < 3; corner++) {
+                    uint64_t vi = v0 + s->mesh_indices[3 * t + corner];
+                    tri_uv[6 * t + 2 * corner] = s->mesh_texcoords[2 * vi]; tri_uv[6 * t + 2 * corner + 1] = s->mesh_texcoords[2 * vi + 1];
+                }
+                tri_has_uv[t] = 1;
+            }
+        }
+        for (uint32_t t = 0; t < s->n_triangles; t++)
+            if (s->tri_texcoords && s->tri_has_texcoords && s->tri_has_texcoords[t]) {
+                for (int k = 0; k < 6; k++) tri_uv[6 * (mesh_tris + t) + k] = s->tri_texcoords[6 * (size_t)t + k];
+                tri_has_uv[mesh_tris + t] = 1;
+            }
+        // material.rs:133 / :141: the reference panics when a mapped material meets a primitive without texture coordinates
+        for (uint32_t i = 0; i < n; i++) {
+            int32_t m = s->material[i];
+            if (mat_maps[2 * m] < 0 && mat_maps[2 * m + 1] < 0) continue;
+            int t = s->prim_type[i];
+            bool ok = t == PT_PRIM_SPHERE || t == PT_PRIM_CUBE || t == PT_PRIM_PLANE;
+            if (t == PT_PRIM_TRIANGLE) ok = tri_has_uv[mesh_tris + (size_t)s->prim_data[i]];
+            if (t == PT_PRIM_MESH || t == PT_PRIM_KDMESH) ok = s->mesh_tri_off[s->prim_data[i] + 1] == s->mesh_tri_off[s->prim_data[i]] || tri_has_uv[s->mesh_tri_off[s->prim_data[i]]];
+            if (!ok) return pt_fail(c, PT_ERR_SCENE, "Texture mapping is not supported for this primitive! (material.rs:133,141)");
+        }
+        if ((rc = pt_upload(c, c->mat_maps, mat_maps)) || (rc = pt_upload(c, c->uv_trans, uv_trans)) || (rc = pt_upload(c, c->tex, texinfo)) ||
+            (rc = pt_upload(c, c->tex_rgb, tex_rgb)) || (rc = pt_upload(c, c->srgb_lut, srgb_lut)) || (rc = pt_upload(c, c->tri_uv, tri_uv)))
+            return rc;
+    }
+
     PtSceneView& v = c->view;
     memset(&v, 0, sizeof v);
     v.n_nodes = n; v.n_lights = s->n_lights;
@@ -483,6 +545,10 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : PT_MODE_FLAT);
     int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + max_blas_depth + 2 : tlas.depth + max_blas_depth + 4;
     v.stack_cap = std::max(cap, 8);
+    if (textured) {
+        v.mat_maps = (const int32_t*)c->mat_maps.p; v.uv_trans = (const double*)c->uv_trans.p; v.tex = (const PtTexInfo*)c->tex.p;
+        v.tex_rgb = (const uint8_t*)c->tex_rgb.p; v.srgb_lut = (const double*)c->srgb_lut.p; v.tri_uv = (const double*)c->tri_uv.p;
+    }
     if ((size_t)v.stack_cap * PT_BLOCK * 4 > 64 * 1024) return pt_fail(c, PT_ERR_SCENE, "traversal stack would not fit in LDS (tree too deep)");
     c->have_scene = true;
     return PT_OK;
@@ -514,25 +580,32 @@ static int pt_check_params(pt_context* c, const pt_camera* cam, const pt_render_
     return PT_OK;
 }
 
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool TEX>
 static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
     size_t lds = (size_t)a.scene.stack_cap * PT_BLOCK * 4;
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS>, PT_BLOCK, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX>, PT_BLOCK, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     uint32_t want = (a.n_work + PT_BLOCK - 1) / PT_BLOCK;
     uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
     *grid_out = grid;
     if (!launch) return hipSuccess;
-    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
     return hipGetLastError();
 }
 
+template <int MODE>
+static hipError_t pt_dispatch_mode(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
+    const bool tex = a.scene.mat_maps != nullptr;
+    if (tex) return stats ? pt_launch<MODE, true, true>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true>(a, n_cu, stream, grid, launch);
+    return stats ? pt_launch<MODE, true, false>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false>(a, n_cu, stream, grid, launch);
+}
+
 static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
-    if (a.scene.mode == PT_MODE_FLAT_NOMESH) return stats ? pt_launch<PT_MODE_FLAT_NOMESH, true>(a, n_cu, stream, grid, launch) : pt_launch<PT_MODE_FLAT_NOMESH, false>(a, n_cu, stream, grid, launch);
-    if (a.scene.mode == PT_MODE_KD) return stats ? pt_launch<PT_MODE_KD, true>(a, n_cu, stream, grid, launch) : pt_launch<PT_MODE_KD, false>(a, n_cu, stream, grid, launch);
-    return stats ? pt_launch<PT_MODE_FLAT, true>(a, n_cu, stream, grid, launch) : pt_launch<PT_MODE_FLAT, false>(a, n_cu, stream, grid, launch);
+    if (a.scene.mode == PT_MODE_FLAT_NOMESH) return pt_dispatch_mode<PT_MODE_FLAT_NOMESH>(a, stats, n_cu, stream, grid, launch);
+    if (a.scene.mode == PT_MODE_KD) return pt_dispatch_mode<PT_MODE_KD>(a, stats, n_cu, stream, grid, launch);
+    return pt_dispatch_mode<PT_MODE_FLAT>(a, stats, n_cu, stream, grid, launch);
 }
 
 static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_params* p, PtRenderArgs* a) {

@@ -9,6 +9,8 @@
 //   tri_v: n_tris  x  9 f64  a, b, c per triangle, 72-byte records (mesh.rs:97-115 expanded once)
 //   tri_n: n_tris  x  9 f64  vertex normals (smooth shading only)
 //   materials: x 10 f64, lights: x 15 f64
+//   textures: RGB8 texels + a 256-entry sRGB->linear table; per-material map indices and uv transform;
+//          per-triangle texture coordinates (6 f64) when a textured material uses the mesh
 //   bvh / bvh_items: the build's own acceleration structure for FLAT mode (two levels: one tree over
 //          the flattened nodes in world space, one tree per mesh in model space)
 //   kd / kd_items: the reference's scene k-d tree, linearised (kdtree/node.rs:13-25), for KD mode
@@ -48,6 +50,11 @@ struct PtMeshInfo {
     uint32_t pad;
 };
 
+struct PtTexInfo {  // one RgbImageBuffer (texture.rs:74-76) inside tex_rgb
+    uint64_t offset;
+    uint32_t width, height;
+};
+
 struct PtSceneView {
     uint32_t n_nodes, n_lights;
     const double* inv;
@@ -68,6 +75,13 @@ struct PtSceneView {
     double kd_extent;  // bounding_box.rs:95-99: squared diagonal of the root bounds
     int32_t mode;
     int32_t stack_cap;  // entries per lane in the traversal stack
+    // texture.rs (all null when the scene has no textured material)
+    const int32_t* mat_maps;   // n_materials x 2: texture index, normal-map index (-1 = none)
+    const double* uv_trans;    // n_materials x 9, row-major Mat3 (material.rs:83)
+    const PtTexInfo* tex;      // per texture
+    const uint8_t* tex_rgb;    // RGB8 texels of all textures
+    const double* srgb_lut;    // 256 entries: (k / 255)^2.2 computed on the host (texture.rs:162-168)
+    const double* tri_uv;      // n_tris x 6: texture coordinates of a, b, c (mesh.rs:30, triangle.rs:18)
 };
 
 struct PtCamera {  // camera.rs:17-31, built on the host (look_at inverse, tan)

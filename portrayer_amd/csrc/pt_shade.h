@@ -17,13 +17,13 @@
 //   slot s of depth d of lane l at frames[(d * PT_FRAME_SLOTS + s) * n_lanes + l]
 //   slots 0-2 ray direction D (later: reflected colour Cr), 3-5 hit point P (3: Schlick
 //   reflectance once the refracted ray is in flight), 6-8 unit normal N, 9-11 colour so far,
-//   12 {material, frame stage}.
+//   12 {material, frame stage}, 13-15 the texel colour of a textured material (material.rs:138-144).
 // Depth PT_SUM_DEPTH (one past the deepest frame) slots 0-2 hold the pixel's running sample sum.
 #pragma once
 
 #include "pt_trace.h"
 
-#define PT_FRAME_SLOTS 13
+#define PT_FRAME_SLOTS 16
 #define PT_MAX_DEPTH 10  // material.rs:12
 #define PT_SUM_DEPTH (PT_MAX_DEPTH + 1)
 #define PT_FRAME_DEPTHS (PT_MAX_DEPTH + 2)
@@ -43,7 +43,7 @@
 
 enum { PT_JITTER_CENTRE = 0, PT_JITTER_RNG = 1 };
 enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_AFTER_LIGHTS = 4 };
-enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2 };
+enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_TEXTURED = 256 };
 
 struct PtRenderArgs {
     PtSceneView scene;
@@ -198,6 +198,101 @@ PT_HD PtVec3 pt_light_position(const PtRenderArgs& a, const PtLane& L, const dou
     return pos + (aa * a_coord + ab * b_coord);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Textures and normal maps (src/texture.rs, consumed at material.rs:109-144). Out of line and entered
+// only for materials that carry a map, so the common untextured path keeps its register budget.
+// ------------------------------------------------------------------------------------------------
+PT_HD PtVec3 pt_texel(const PtTexInfo* tex, const uint8_t* rgb, int32_t id, double u, double v) {  // texture.rs:96-141
+    long long width = tex[id].width, height = tex[id].height;
+    double fx = u * (double)(width - 1), fy = v * (double)(height - 1);
+    // Rust `as i64`: truncation toward zero, saturating, NaN -> 0
+    long long x = fx != fx ? 0 : (fx >= 9.2233720368547758e18 ? 0x7fffffffffffffffLL : (fx <= -9.2233720368547758e18 ? (-0x7fffffffffffffffLL - 1) : (long long)fx));
+    long long y = fy != fy ? 0 : (fy >= 9.2233720368547758e18 ? 0x7fffffffffffffffLL : (fy <= -9.2233720368547758e18 ? (-0x7fffffffffffffffLL - 1) : (long long)fy));
+    x %= width; if (x < 0) x += width;  // rem_euclid
+    y %= height; if (y < 0) y += height;
+    const uint8_t* px = rgb + tex[id].offset + 3 * ((size_t)y * (size_t)width + (size_t)x);
+    return pt_v3((double)px[0], (double)px[1], (double)px[2]);  // 0..255, not yet divided
+}
+
+struct PtMat3 {
+    PtVec3 c0, c1, c2;  // columns (Mat3::from_col_arrays)
+};
+PT_HD PtVec3 pt_mat3_mul(const PtMat3& m, PtVec3 v) {  // row dot products, left to right
+    return pt_v3((m.c0.x * v.x + m.c1.x * v.y) + m.c2.x * v.z, (m.c0.y * v.x + m.c1.y * v.y) + m.c2.y * v.z, (m.c0.z * v.x + m.c1.z * v.y) + m.c2.z * v.z);
+}
+
+// type / sub / local / t identify the hit (as in PT_ST_CLOSEST_DONE); p, n = its model-space point and
+// raw normal. Returns the diffuse colour (texel or *kd unchanged) and, when the material has a normal
+// map, the shading normal (NOT multiplied by the node's normal_trans: quirk Q12 of the reference).
+PT_NOINLINE void pt_apply_maps(const PtTexInfo* tex, const uint8_t* tex_rgb, const double* lut, const double* uv_trans9, const double* tri_v,
+                               const double* tri_uv, uint32_t type, uint32_t sub, double ox, double oy, double oz, double dx, double dy, double dz,
+                               double px, double py, double pz, double nx, double ny, double nz, int32_t tex_id, int32_t nmap_id,
+                               double* kd_out, double* n_out, int* has_n) {
+    PtVec3 p = pt_v3(px, py, pz), n = pt_v3(nx, ny, nz);
+    double u = 0.0, v = 0.0;
+    PtMat3 tbn;
+    tbn.c0 = pt_v3(1.0, 0.0, 0.0); tbn.c1 = pt_v3(0.0, 1.0, 0.0); tbn.c2 = pt_v3(0.0, 0.0, 1.0);
+    if (type == PT_SPHERE || type == PT_CUBE) {
+        PtVec3 fn = n;  // sphere: normal = hit point; cube: the face normal
+        if (type == PT_SPHERE) {  // sphere.rs:53-61
+            const double PI = 3.14159265358979323846;
+            u = (PI + atan2(-p.z, p.x)) / (2.0 * PI);
+            v = acos(p.y) / PI;
+        } else {  // cube.rs:46-66, :84-112
+            const double ax_u[6] = {-1, 1, 1, 1, 1, -1}, ax_v[6] = {1, 1, -1, 1, 1, 1};
+            const double off_u[6] = {1.0 / 2.0, 0.0, 1.0 / 4.0, 1.0 / 4.0, 1.0 / 4.0, 3.0 / 4.0};
+            const double off_v[6] = {1.0 / 3.0, 1.0 / 3.0, 0.0, 2.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0};
+            double fu, fv;
+            if (fn.x != 0.0) { fu = p.z; fv = p.y; } else if (fn.y != 0.0) { fu = p.x; fv = p.z; } else { fu = p.x; fv = p.y; }
+            double nu = fu * ax_u[sub] + 0.5, nv = 0.5 - fv * ax_v[sub];
+            u = nu / 4.0 + off_u[sub];
+            v = nv / 3.0 + off_v[sub];
+        }
+        // sphere.rs:75-96 / cube.rs:114-137
+        PtVec3 to_top = pt_normalized(pt_v3(0.0, 1.0, 0.0) - p);
+        if (fabs(to_top.x) < PT_EPSILON && fabs(to_top.z) < PT_EPSILON) {
+            tbn.c0 = pt_v3(1.0, 0.0, 0.0); tbn.c1 = fn; tbn.c2 = fn.y > 0.0 ? pt_v3(0.0, 0.0, 1.0) : pt_v3(0.0, 0.0, -1.0);
+        } else {
+            PtVec3 ht = pt_cross(to_top, fn);
+            tbn.c0 = ht; tbn.c1 = fn; tbn.c2 = pt_cross(fn, ht);
+        }
+    } else if (type == PT_PLANE) {  // plane.rs:40-46
+        u = p.x + 0.5; v = p.z + 0.5;
+    } else {  // triangle with texture coordinates: triangle.rs:90-138
+        const double* tv = tri_v + 9 * (size_t)sub;
+        const double* q = tri_uv + 6 * (size_t)sub;
+        PtRay local; local.o = pt_v3(ox, oy, oz); local.d = pt_v3(dx, dy, dz);
+        double t2, beta, gamma;
+        pt_triangle_hit(tv, local, -INFINITY, INFINITY, &t2, &beta, &gamma);
+        double alpha = 1.0 - beta - gamma;
+        double uu = (q[0] * alpha + q[2] * beta) + q[4] * gamma, vv = (q[1] * alpha + q[3] * beta) + q[5] * gamma;
+        u = uu; v = 1.0 - vv;
+        PtVec3 A = pt_v3(tv[0], tv[1], tv[2]), B = pt_v3(tv[3], tv[4], tv[5]), C = pt_v3(tv[6], tv[7], tv[8]);
+        PtVec3 e1 = B - A, e2 = C - A;
+        double du1 = q[2] - q[0], dv1 = q[3] - q[1], du2 = q[4] - q[0], dv2 = q[5] - q[1];
+        PtVec3 tangent = pt_v3(dv2 * e1.x - dv1 * e2.x, dv2 * e1.y - dv1 * e2.y, dv2 * e1.z - dv1 * e2.z);
+        PtVec3 bitangent = pt_v3(-du2 * e1.x + du1 * e2.x, -du2 * e1.y + du1 * e2.y, -du2 * e1.z + du1 * e2.z);
+        double coeff = du1 * dv2 - du2 * dv1;
+        tbn.c0 = pt_normalized(tangent / coeff); tbn.c1 = pt_normalized(n); tbn.c2 = pt_normalized(bitangent / coeff);
+    }
+    // material.rs:113-117: uv_trans * (u, v, 1)
+    double tu = (uv_trans9[0] * u + uv_trans9[1] * v) + uv_trans9[2] * 1.0;
+    double tv2 = (uv_trans9[3] * u + uv_trans9[4] * v) + uv_trans9[5] * 1.0;
+    *has_n = 0;
+    if (nmap_id >= 0) {  // texture.rs:192-221 + material.rs:126-132
+        PtVec3 c = pt_texel(tex, tex_rgb, nmap_id, tu, tv2) / 255.0;
+        PtVec3 norm = pt_v3(2.0 * c.x - 1.0, 2.0 * c.y - 1.0, -(2.0 * c.z - 1.0));
+        PtVec3 tex_norm = pt_v3(norm.x, -norm.z, -norm.y);  // normal_to_rh * norm (a signed permutation: exact)
+        PtVec3 shading = pt_mat3_mul(tbn, pt_normalized(tex_norm));
+        n_out[0] = shading.x; n_out[1] = shading.y; n_out[2] = shading.z;
+        *has_n = 1;
+    }
+    if (tex_id >= 0) {  // texture.rs:162-168 through the host-built (k / 255)^2.2 table
+        PtVec3 c = pt_texel(tex, tex_rgb, tex_id, tu, tv2);
+        kd_out[0] = lut[(int)c.x]; kd_out[1] = lut[(int)c.y]; kd_out[2] = lut[(int)c.z];
+    }
+}
+
 // Runs the lane's interpreter until it needs a ray traced (L.has_ray) or its pixel is finished
 // (L.work == PT_IDLE). `hit` is the result of the ray the lane traced last.
 #ifdef PT_ADVANCE_NOINLINE  // measured slower at every occupancy (profiles/r01/notes.md)
@@ -205,7 +300,8 @@ PT_HD PtVec3 pt_light_position(const PtRenderArgs& a, const PtLane& L, const dou
 #else
 #define PT_ADVANCE_ATTR PT_HD
 #endif
-template <bool STATS>
+// TEX = false compiles the texture / normal-map path out (scenes without mapped materials).
+template <bool STATS, bool TEX>
 PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt) {
     const PtSceneView& sc = a.scene;
     L.has_ray = false;
@@ -228,7 +324,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             const double* m = sc.materials + 10 * (size_t)mat;
             double reflectivity = m[7], ior = m[9];
             PtVec3 color = fr.load3(L.depth, 9);
-            if (fstage == PT_FS_WAIT_REFRACT) {  // material.rs:305-309
+            if ((fstage & PT_FS_STAGE_MASK) == PT_FS_WAIT_REFRACT) {  // material.rs:305-309
                 PtVec3 reflected = fr.load3(L.depth, 0);
                 double schlick = fr.at(L.depth, 3);
                 double transmittance = 1.0 - schlick;
@@ -271,7 +367,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             }
             fr.store3(L.depth, 0, value);
             fr.at(L.depth, 3) = schlick;
-            fr.store_tag(L.depth, mat, PT_FS_WAIT_REFRACT);
+            fr.store_tag(L.depth, mat, (fstage & PT_FS_TEXTURED) | PT_FS_WAIT_REFRACT);
             L.ray.o = P; L.ray.d = refract_dir;
             L.depth++;
             L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
@@ -333,13 +429,26 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             PT_FENCE;
             PtVec3 Nw = pt_xform_dir(sc.nrm + 9 * (size_t)hit.node, 3, n);
             PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
+            const double* m = sc.materials + 10 * (size_t)mat;
+            PtVec3 kd = pt_v3(m[0], m[1], m[2]);
+            uint32_t ftag = 0;
+            if (TEX && sc.mat_maps && (sc.mat_maps[2 * mat] >= 0 || sc.mat_maps[2 * mat + 1] >= 0)) {  // material.rs:109-144
+                double kdv[3] = {kd.x, kd.y, kd.z}, nv[3];
+                int has_n;
+                pt_apply_maps(sc.tex, sc.tex_rgb, sc.srgb_lut, sc.uv_trans + 9 * (size_t)mat, sc.tri_v, sc.tri_uv, type, hit.sub,
+                              local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z, p.x, p.y, p.z, n.x, n.y, n.z,
+                              sc.mat_maps[2 * mat], sc.mat_maps[2 * mat + 1], kdv, nv, &has_n);
+                kd = pt_v3(kdv[0], kdv[1], kdv[2]);
+                if (has_n) N = pt_v3(nv[0], nv[1], nv[2]);
+                fr.store3(L.depth, 13, kd);
+                ftag = PT_FS_TEXTURED;
+            }
             fr.store3(L.depth, 6, N);
             PT_FENCE;
-            const double* m = sc.materials + 10 * (size_t)mat;
-            PtVec3 color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * pt_v3(m[0], m[1], m[2]);  // material.rs:148
+            PtVec3 color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * kd;  // material.rs:148
             fr.store3(L.depth, 0, L.ray.d);
             fr.store3(L.depth, 9, color);
-            fr.store_tag(L.depth, mat, 0);
+            fr.store_tag(L.depth, mat, ftag);
             L.light = 0;
             L.stage = PT_ST_LIGHT;
             continue;
@@ -371,7 +480,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 uint32_t mat, fstage;
                 fr.load_tag(L.depth, &mat, &fstage);
                 const double* m = sc.materials + 10 * (size_t)mat;
-                PtVec3 kd = pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
+                PtVec3 kd = (TEX && (fstage & PT_FS_TEXTURED)) ? fr.load3(L.depth, 13) : pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
                 PtVec3 hit_to_light = lpos - P;
                 double light_dist = pt_length(hit_to_light);
                 PtVec3 light_dir = hit_to_light / light_dist;
@@ -413,7 +522,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 L.draw += 2;
                 reflect_dir = reflect_dir + (u_basis * u_coord + v_basis * v_coord);
             }
-            fr.store_tag(L.depth, mat, PT_FS_WAIT_REFLECT);
+            fr.store_tag(L.depth, mat, (fstage & PT_FS_TEXTURED) | PT_FS_WAIT_REFLECT);
             if (L.depth + 1 > PT_MAX_DEPTH) {  // depth-11 ray: its colour is always the background
                 if (STATS) cnt->depth11_skipped++;
                 L.depth++;

@@ -39,6 +39,9 @@ class PhSceneDesc(C.Structure):
         ("mesh_has_normals", _u8p), ("mesh_indices", _up),
         ("n_triangles", C.c_uint32), ("tri_vertices", _dp), ("tri_normals", _dp), ("tri_has_normals", _u8p),
         ("n_materials", C.c_uint32), ("materials", _dp), ("n_lights", C.c_uint32), ("lights", _dp), ("ambient", C.c_double * 3),
+        ("mesh_texcoords", _dp), ("mesh_has_texcoords", _u8p), ("tri_texcoords", _dp), ("tri_has_texcoords", _u8p),
+        ("material_texture", _ip), ("material_normal_map", _ip), ("material_uv_trans", _dp),
+        ("n_textures", C.c_uint32), ("texture_size", _up), ("texture_offset", _u64p), ("texture_rgb", _u8p),
     ]
 
 
@@ -116,6 +119,13 @@ class Scene:
         s.n_materials = int(keep["n_materials"]); s.materials = _p(keep["materials"], _dp)
         s.n_lights = int(keep["n_lights"]); s.lights = _p(keep["lights"], _dp)
         s.ambient = (C.c_double * 3)(*map(float, keep["ambient"]))
+        if keep.get("n_textures"):
+            s.mesh_texcoords = _p(keep["mesh_texcoords"], _dp); s.mesh_has_texcoords = _p(keep["mesh_has_texcoords"], _u8p)
+            s.tri_texcoords = _p(keep["tri_texcoords"], _dp); s.tri_has_texcoords = _p(keep["tri_has_texcoords"], _u8p)
+            s.material_texture = _p(keep["material_texture"], _ip); s.material_normal_map = _p(keep["material_normal_map"], _ip)
+            s.material_uv_trans = _p(keep["material_uv_trans"], _dp)
+            s.n_textures = int(keep["n_textures"]); s.texture_size = _p(keep["texture_size"], _up)
+            s.texture_offset = _p(keep["texture_offset"], _u64p); s.texture_rgb = _p(keep["texture_rgb"], _u8p)
         h = C.c_void_p()
         _check(lib().ph_scene_create(C.byref(s), C.byref(h)), "ph_scene_create")
         return Scene(h)

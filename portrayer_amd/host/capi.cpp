@@ -41,10 +41,27 @@ extern "C" int ph_scene_create(const ph_scene_desc* d, ph_scene** out) {
         *out = nullptr;
         const uint32_t n = d->n_nodes;
         if (n == 0 || d->root >= n) return bad("scene needs a root node");
+        std::vector<Arc<texture::Texture>> textures;     // one of each per image: a material picks the view it needs
+        std::vector<Arc<texture::NormalMap>> normal_maps;
+        for (uint32_t t = 0; t < d->n_textures; t++) {
+            auto buf = texture::RgbImageBuffer::from_pixels(d->texture_size[2 * t], d->texture_size[2 * t + 1], d->texture_rgb + d->texture_offset[t]);
+            textures.push_back(std::make_shared<texture::Texture>(texture::Texture{texture::ImageTexture{buf}}));
+            normal_maps.push_back(std::make_shared<texture::NormalMap>(texture::NormalMap{std::move(buf)}));
+        }
         std::vector<Arc<material::Material>> mats;
         for (uint32_t i = 0; i < d->n_materials; i++) {
             const double* m = d->materials + 10 * (size_t)i;
-            mats.push_back(std::make_shared<material::Material>(material::Material{Rgb{m[0], m[1], m[2]}, Rgb{m[3], m[4], m[5]}, m[6], m[7], m[8], m[9]}));
+            auto mat = std::make_shared<material::Material>(material::Material{Rgb{m[0], m[1], m[2]}, Rgb{m[3], m[4], m[5]}, m[6], m[7], m[8], m[9]});
+            if (d->material_texture && d->material_texture[i] >= 0) {
+                if ((uint32_t)d->material_texture[i] >= d->n_textures) throw std::runtime_error("texture index out of range");
+                mat->texture = textures[d->material_texture[i]];
+            }
+            if (d->material_normal_map && d->material_normal_map[i] >= 0) {
+                if ((uint32_t)d->material_normal_map[i] >= d->n_textures) throw std::runtime_error("texture index out of range");
+                mat->normals = normal_maps[d->material_normal_map[i]];
+            }
+            if (d->material_uv_trans) for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) mat->uv_trans.m[r][k] = d->material_uv_trans[9 * (size_t)i + 3 * r + k];
+            mats.push_back(std::move(mat));
         }
         std::vector<Arc<primitive::MeshData>> meshes;
         for (uint32_t i = 0; i < d->n_meshes; i++) {
@@ -55,7 +72,10 @@ extern "C" int ph_scene_create(const ph_scene_desc* d, ph_scene** out) {
                 for (uint64_t v = v0; v < v1; v++) nrm.emplace_back(d->mesh_normals[3 * v], d->mesh_normals[3 * v + 1], d->mesh_normals[3 * v + 2]);
             std::vector<std::array<uint32_t, 3>> tris;
             for (uint64_t t = t0; t < t1; t++) tris.push_back({d->mesh_indices[3 * t], d->mesh_indices[3 * t + 1], d->mesh_indices[3 * t + 2]});
-            meshes.push_back(primitive::MeshData::create(std::move(pos), std::move(tris), std::move(nrm)));
+            std::vector<Uv> uvs;
+            if (d->mesh_has_texcoords && d->mesh_has_texcoords[i] && d->mesh_texcoords)
+                for (uint64_t v = v0; v < v1; v++) uvs.push_back(Uv{d->mesh_texcoords[2 * v], d->mesh_texcoords[2 * v + 1]});
+            meshes.push_back(primitive::MeshData::create(std::move(pos), std::move(tris), std::move(nrm), std::move(uvs)));
         }
         // Children must exist before their parents are finished: build in reverse topological order by
         // memoised recursion (the description is a DAG; shared nodes become shared Arcs).
@@ -91,6 +111,10 @@ extern "C" int ph_scene_create(const ph_scene_desc* d, ph_scene** out) {
                     if (d->tri_has_normals && d->tri_has_normals[k] && d->tri_normals) {
                         const double* q = d->tri_normals + 9 * (size_t)k;
                         tri.normals = std::array<Vec3, 3>{Vec3(q[0], q[1], q[2]), Vec3(q[3], q[4], q[5]), Vec3(q[6], q[7], q[8])};
+                    }
+                    if (d->tri_has_texcoords && d->tri_has_texcoords[k] && d->tri_texcoords) {
+                        const double* q = d->tri_texcoords + 6 * (size_t)k;
+                        tri.tex_coords = std::array<Uv, 3>{Uv{q[0], q[1]}, Uv{q[2], q[3]}, Uv{q[4], q[5]}};
                     }
                     node = scene::SceneNode::from(scene::Geometry::create(tri, mat));
                     break;

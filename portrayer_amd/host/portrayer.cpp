@@ -110,8 +110,11 @@ Vec3 math::transformed_direction(Vec3 v, const Mat4& t) {
 // ------------------------------------------------------------------------------------------------
 namespace primitive {
 
-Arc<MeshData> MeshData::create(std::vector<Vec3> positions, std::vector<std::array<uint32_t, 3>> triangles, std::vector<Vec3> normals) {
+Arc<MeshData> MeshData::create(std::vector<Vec3> positions, std::vector<std::array<uint32_t, 3>> triangles, std::vector<Vec3> normals,
+                               std::vector<Uv> tex_coords) {
     if (positions.empty()) throw Panic("Meshes must have at least one vertex");  // mesh.rs:71
+    if (!tex_coords.empty() && tex_coords.size() != positions.size())  // mesh.rs:77-79
+        throw Panic("If meshes have texture coordinates, they must have enough for all vertices");
     for (const auto& t : triangles)
         for (uint32_t i : t)
             if (i >= positions.size()) throw Panic("index out of bounds: mesh triangle refers to a missing vertex");
@@ -121,6 +124,7 @@ Arc<MeshData> MeshData::create(std::vector<Vec3> positions, std::vector<std::arr
     md->positions_ = std::move(positions);
     md->triangles_ = std::move(triangles);
     md->normals_ = std::move(normals);
+    md->tex_coords_ = std::move(tex_coords);
     md->min_ = mn; md->max_ = mx;
     return md;
 }
@@ -129,8 +133,9 @@ Arc<MeshData> MeshData::load_obj(const std::string& path) {
     std::ifstream in(path);
     if (!in) throw std::runtime_error("could not open OBJ file: " + path);
     std::vector<Vec3> pos, nrm;
-    size_t n_tex = 0;
+    std::vector<Uv> tex;
     std::vector<Vec3> out_pos, out_nrm;
+    std::vector<Uv> out_tex;
     std::vector<std::array<uint32_t, 3>> tris;
     std::map<std::tuple<long, long, long>, uint32_t> index_map;
     bool seen_faces = false;
@@ -147,7 +152,11 @@ Arc<MeshData> MeshData::load_obj(const std::string& path) {
         if (!(ss >> tag)) continue;
         if (tag == "v") pos.push_back(parse3(ss));
         else if (tag == "vn") nrm.push_back(parse3(ss));
-        else if (tag == "vt") n_tex++;
+        else if (tag == "vt") {
+            std::string a, b;
+            ss >> a >> b;
+            tex.push_back(Uv{(double)std::strtof(a.c_str(), nullptr), (double)std::strtof(b.c_str(), nullptr)});
+        }
         else if (tag == "o" || tag == "g") { if (seen_faces) break; }  // models[0] only (mesh.rs:60)
         else if (tag == "f") {
             seen_faces = true;
@@ -162,7 +171,7 @@ Arc<MeshData> MeshData::load_obj(const std::string& path) {
                         k++; start = i + 1;
                     }
                 long v = idx[0] > 0 ? idx[0] - 1 : (long)pos.size() + idx[0];
-                long vt = idx[1] > 0 ? idx[1] - 1 : (idx[1] < 0 ? (long)n_tex + idx[1] : -1);
+                long vt = idx[1] > 0 ? idx[1] - 1 : (idx[1] < 0 ? (long)tex.size() + idx[1] : -1);
                 long vn = idx[2] > 0 ? idx[2] - 1 : (idx[2] < 0 ? (long)nrm.size() + idx[2] : -1);
                 if (v < 0 || (size_t)v >= pos.size()) throw std::runtime_error("OBJ face refers to a missing vertex: " + path);
                 auto key = std::make_tuple(v, vt, vn);
@@ -171,6 +180,7 @@ Arc<MeshData> MeshData::load_obj(const std::string& path) {
                     it = index_map.emplace(key, (uint32_t)out_pos.size()).first;
                     out_pos.push_back(pos[(size_t)v]);
                     if (vn >= 0 && (size_t)vn < nrm.size()) out_nrm.push_back(nrm[(size_t)vn]);
+                    if (vt >= 0 && (size_t)vt < tex.size()) out_tex.push_back(tex[(size_t)vt]);
                 }
                 corner.push_back(it->second);
             }
@@ -178,7 +188,8 @@ Arc<MeshData> MeshData::load_obj(const std::string& path) {
         }
     }
     if (out_nrm.size() != out_pos.size()) out_nrm.clear();
-    return create(std::move(out_pos), std::move(tris), std::move(out_nrm));
+    if (out_tex.size() != out_pos.size()) out_tex.clear();
+    return create(std::move(out_pos), std::move(tris), std::move(out_nrm), std::move(out_tex));
 }
 
 Mesh::Mesh(Arc<MeshData> d, Shading s) : data(std::move(d)), shading(s) {
@@ -192,6 +203,23 @@ KDMesh::KDMesh(const Arc<MeshData>& d, Shading s) : data(d), shading(s) {
         throw Panic("index out of bounds: smooth shading needs a vertex normal for each vertex");
 }
 }  // namespace primitive
+
+// ------------------------------------------------------------------------------------------------
+// texture
+// ------------------------------------------------------------------------------------------------
+namespace texture {
+RgbImageBuffer RgbImageBuffer::open(const std::string& path) {
+    RgbImageBuffer b;
+    if (!detail::png_read(path, &b.width, &b.height, &b.rgb)) throw std::runtime_error("could not open texture image: " + path);
+    return b;
+}
+RgbImageBuffer RgbImageBuffer::from_pixels(size_t width, size_t height, const uint8_t* rgb) {
+    RgbImageBuffer b;
+    b.width = width; b.height = height;
+    b.rgb.assign(rgb, rgb + width * height * 3);
+    return b;
+}
+}  // namespace texture
 
 // ------------------------------------------------------------------------------------------------
 // scene
@@ -426,8 +454,17 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
     std::map<const primitive::MeshData*, int32_t> mesh_id;
     std::vector<const primitive::MeshData*> meshes;
     std::map<const material::Material*, int32_t> mat_id;
-    std::vector<double> materials, tri_v, tri_n;
-    bool any_tri_normals = false;
+    std::vector<double> materials, tri_v, tri_n, tri_uv, uv_trans;
+    std::vector<uint8_t> tri_has_uv;
+    std::vector<int32_t> mat_tex, mat_nmap;
+    std::map<const texture::RgbImageBuffer*, int32_t> tex_id;
+    std::vector<const texture::RgbImageBuffer*> textures;
+    auto texture_index = [&](const texture::RgbImageBuffer* b) -> int32_t {
+        auto it = tex_id.find(b);
+        if (it == tex_id.end()) { it = tex_id.emplace(b, (int32_t)textures.size()).first; textures.push_back(b); }
+        return it->second;
+    };
+    bool any_tri_normals = false, any_tri_uv = false;
     for (size_t i = 0; i < n; i++) {
         const FlatSceneNode& fn = flat_.root[i];
         std::memcpy(&trans[16 * i], fn.trans.m, 128);
@@ -450,6 +487,9 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
                 tri_n.push_back(nn.x); tri_n.push_back(nn.y); tri_n.push_back(nn.z);
             }
             if (t.normals) { flags[i] = 1; any_tri_normals = true; }
+            for (int k = 0; k < 3; k++) { tri_uv.push_back(t.tex_coords ? (*t.tex_coords)[k].u : 0.0); tri_uv.push_back(t.tex_coords ? (*t.tex_coords)[k].v : 0.0); }
+            tri_has_uv.push_back(t.tex_coords ? 1 : 0);
+            if (t.tex_coords) any_tri_uv = true;
         }
         const material::Material* m = fn.geometry.material.get();
         if (!m) throw Panic("geometry without a material");
@@ -459,12 +499,15 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
             const double row[10] = {m->diffuse.r, m->diffuse.g, m->diffuse.b, m->specular.r, m->specular.g, m->specular.b,
                                     m->shininess, m->reflectivity, m->glossy_side_length, m->refraction_index};
             materials.insert(materials.end(), row, row + 10);
+            mat_tex.push_back(m->texture ? texture_index(&m->texture->image.buffer) : -1);
+            mat_nmap.push_back(m->normals ? texture_index(&m->normals->buffer) : -1);
+            for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) uv_trans.push_back(m->uv_trans.m[r][k]);
         }
         mat[i] = mit->second;
     }
     std::vector<uint64_t> vert_off{0}, tri_off{0};
-    std::vector<double> positions, normals, mesh_bounds_inv;
-    std::vector<uint8_t> has_normals;
+    std::vector<double> positions, normals, mesh_bounds_inv, texcoords;
+    std::vector<uint8_t> has_normals, has_texcoords;
     std::vector<uint32_t> indices;
     for (const primitive::MeshData* m : meshes) {
         for (const Vec3& p : m->positions()) { positions.push_back(p.x); positions.push_back(p.y); positions.push_back(p.z); }
@@ -474,6 +517,9 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
             normals.push_back(nn.x); normals.push_back(nn.y); normals.push_back(nn.z);
         }
         has_normals.push_back(hn ? 1 : 0);
+        bool ht = m->tex_coords().size() == m->positions().size();
+        for (size_t v = 0; v < m->positions().size(); v++) { texcoords.push_back(ht ? m->tex_coords()[v].u : 0.0); texcoords.push_back(ht ? m->tex_coords()[v].v : 0.0); }
+        has_texcoords.push_back(ht ? 1 : 0);
         for (const auto& t : m->triangles()) { indices.push_back(t[0]); indices.push_back(t[1]); indices.push_back(t[2]); }
         vert_off.push_back(vert_off.back() + m->positions().size());
         tri_off.push_back(tri_off.back() + m->triangles().size());
@@ -501,6 +547,20 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
     s.n_materials = (uint32_t)(materials.size() / 10); s.materials = materials.data();
     s.n_lights = (uint32_t)flat_.lights.size(); s.lights = lights.data();
     s.ambient[0] = flat_.ambient.r; s.ambient[1] = flat_.ambient.g; s.ambient[2] = flat_.ambient.b;
+    std::vector<uint32_t> tex_size;
+    std::vector<uint64_t> tex_off;
+    std::vector<uint8_t> tex_rgb;
+    if (!textures.empty()) {
+        for (const texture::RgbImageBuffer* b : textures) {
+            tex_size.push_back((uint32_t)b->width); tex_size.push_back((uint32_t)b->height);
+            tex_off.push_back(tex_rgb.size());
+            tex_rgb.insert(tex_rgb.end(), b->rgb.begin(), b->rgb.end());
+        }
+        s.mesh_texcoords = texcoords.data(); s.mesh_has_texcoords = has_texcoords.data();
+        s.tri_texcoords = any_tri_uv ? tri_uv.data() : nullptr; s.tri_has_texcoords = any_tri_uv ? tri_has_uv.data() : nullptr;
+        s.material_texture = mat_tex.data(); s.material_normal_map = mat_nmap.data(); s.material_uv_trans = uv_trans.data();
+        s.n_textures = (uint32_t)textures.size(); s.texture_size = tex_size.data(); s.texture_offset = tex_off.data(); s.texture_rgb = tex_rgb.data();
+    }
 
     int rc = pt_context_create(device, &ctx_);
     if (rc != PT_OK) throw std::runtime_error("pt_context_create failed (" + std::to_string(rc) + "): no usable MI355X; this path has no CPU fallback");

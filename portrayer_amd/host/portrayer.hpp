@@ -127,9 +127,38 @@ struct Mat4 {
     Mat4 transposed() const;
     Mat4 operator*(const Mat4& o) const;
 };
+struct Mat3 {  // only what Material::uv_trans needs (material.rs:83)
+    double m[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    static Mat3 identity() { return Mat3(); }
+    static Mat3 scaling_3d(Vec3 s) { Mat3 r; r.m[0][0] = s.x; r.m[1][1] = s.y; r.m[2][2] = s.z; return r; }
+};
 Vec3 transformed_point(Vec3 v, const Mat4& m);      // math.rs:45-47
 Vec3 transformed_direction(Vec3 v, const Mat4& m);  // math.rs:49-51
 }  // namespace math
+
+// ------------------------------------------------------------------------------------------------
+namespace texture {  // src/texture.rs
+struct RgbImageBuffer {  // texture.rs:74-141: the decoded RGB8 pixels, no colour correction
+    size_t width = 0, height = 0;
+    std::vector<uint8_t> rgb;
+    static RgbImageBuffer open(const std::string& path);  // PNG (the reference's `image` crate also reads JPEG)
+    static RgbImageBuffer from_pixels(size_t width, size_t height, const uint8_t* rgb);
+};
+struct ImageTexture {  // texture.rs:143-169: sampled colours go sRGB -> linear with powf(2.2)
+    RgbImageBuffer buffer;
+    static ImageTexture open(const std::string& path) { return ImageTexture{RgbImageBuffer::open(path)}; }
+};
+// texture.rs:23-29 `enum Texture {FnTex, Image}`: only image textures can run on the GPU; a
+// function texture would have to be baked into an image first.
+struct Texture {
+    ImageTexture image;
+    static Texture from(ImageTexture img) { return Texture{std::move(img)}; }
+};
+struct NormalMap {  // texture.rs:171-221
+    RgbImageBuffer buffer;
+    static NormalMap open(const std::string& path) { return NormalMap{RgbImageBuffer::open(path)}; }
+};
+}  // namespace texture
 
 // ------------------------------------------------------------------------------------------------
 namespace material {  // src/material.rs
@@ -139,13 +168,16 @@ constexpr double WINDOW_GLASS_REFRACTION_INDEX = 1.51;
 constexpr double OPTICAL_GLASS_REFRACTION_INDEX = 1.92;
 constexpr double DIAMOND_REFRACTION_INDEX = 2.42;
 
-struct Material {  // material.rs:50-86; texture / uv_trans / normals are not part of this path yet
+struct Material {  // material.rs:50-86
     math::Rgb diffuse;
     math::Rgb specular;
     double shininess = 0.0;
     double reflectivity = 0.0;
     double glossy_side_length = 0.0;
     double refraction_index = 0.0;
+    Arc<texture::Texture> texture;     // Option<Arc<Texture>>: diffuse colour sampled from an image
+    math::Mat3 uv_trans;               // applied to the texture coordinate before sampling
+    Arc<texture::NormalMap> normals;   // Option<Arc<NormalMap>>: shading normal sampled from an image
 };
 }  // namespace material
 
@@ -175,7 +207,8 @@ struct Cone {};
 struct Triangle {  // triangle.rs:8-26
     math::Vec3 a, b, c;
     std::optional<std::array<math::Vec3, 3>> normals;
-    static Triangle flat(math::Vec3 a, math::Vec3 b, math::Vec3 c) { return Triangle{a, b, c, std::nullopt}; }
+    std::optional<std::array<math::Uv, 3>> tex_coords;
+    static Triangle flat(math::Vec3 a, math::Vec3 b, math::Vec3 c) { return Triangle{a, b, c, std::nullopt, std::nullopt}; }
 };
 
 enum class Shading { Flat, Smooth };  // mesh.rs:11-18
@@ -186,7 +219,8 @@ class MeshData {  // mesh.rs:21-34
     // to f64, fan triangulation, vertices de-duplicated per (v, vt, vn).
     static Arc<MeshData> load_obj(const std::string& path);
     static Arc<MeshData> create(std::vector<math::Vec3> positions, std::vector<std::array<uint32_t, 3>> triangles,
-                                std::vector<math::Vec3> normals);
+                                std::vector<math::Vec3> normals, std::vector<math::Uv> tex_coords = {});
+    const std::vector<math::Uv>& tex_coords() const { return tex_coords_; }
     const std::vector<math::Vec3>& positions() const { return positions_; }
     const std::vector<math::Vec3>& normals() const { return normals_; }
     const std::vector<std::array<uint32_t, 3>>& triangles() const { return triangles_; }
@@ -195,6 +229,7 @@ class MeshData {  // mesh.rs:21-34
 
    private:
     std::vector<math::Vec3> positions_, normals_;
+    std::vector<math::Uv> tex_coords_;
     std::vector<std::array<uint32_t, 3>> triangles_;
     math::Vec3 min_, max_;
 };

@@ -18,7 +18,7 @@ files = {}
 for l in text:
     m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
     if m: files[m.group(1)] = (m.group(3) or m.group(2))
-start = next(i for i, l in enumerate(text) if l.startswith("_Z16pt_render_kernelILi1ELb0EEv12PtRenderArgs:"))
+start = next(i for i, l in enumerate(text) if l.startswith("_Z16pt_render_kernelILi3ELb0ELb0EEv12PtRenderArgs:"))
 end = start
 while "s_endpgm" not in text[end]: end += 1
 loc = None; cnt = collections.Counter()

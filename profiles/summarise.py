@@ -14,7 +14,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
     for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "pt_render_kernel<" in r["Kernel_Name"] and "false>" in r["Kernel_Name"]:
+            if "pt_render_kernel<" in r["Kernel_Name"] and ", false, " in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}

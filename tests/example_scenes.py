@@ -152,3 +152,40 @@ EXAMPLES = {
     "entering-the-mirror-dimension": mirror_dimension,
     "big-scene": big_scene,
 }
+
+
+def normal_mapping(light_pos=(0.0, 8.0, 10.0)):
+    """examples/normal-mapping.rs:20-171 (texture + normal maps on Plane, Cube, Sphere)."""
+    import os
+    from scene_dsl import Texture
+    tex = lambda name: Texture.open(os.path.join(ASSETS, name))
+    tex_plane, nrm_plane = tex("Terracotta_Tiles_002_Base_Color.jpg"), tex("Terracotta_Tiles_002_Normal.jpg")
+    tex_sphere, nrm_sphere = tex("Rock_033_baseColor_2.jpg"), tex("Rock_033_normal_2.jpg")
+    tex_cube, nrm_cube = tex("Stone_Wall_007_COLOR_cubemap.jpg"), tex("Stone_Wall_007_NORM_cubemap.jpg")
+    d = (0.37168, 0.236767, 0.692066)
+    mat_tex_plane = Material(diffuse=d, specular=(0.4, 0.4, 0.4), shininess=25.0, texture=tex_plane)
+    mat_tex_plane_norm = Material(diffuse=d, specular=(0.4, 0.4, 0.4), shininess=25.0, texture=tex_plane, normals=nrm_plane)
+    mat_tex_sphere = Material(diffuse=d, specular=(0.6, 0.6, 0.6), shininess=25.0, texture=tex_sphere)
+    mat_tex_sphere_norm = Material(diffuse=d, specular=(0.6, 0.6, 0.6), shininess=25.0, texture=tex_sphere, normals=nrm_sphere)
+    mat_tex_cube = Material(diffuse=d, specular=(0.3, 0.3, 0.3), shininess=25.0, texture=tex_cube)
+    mat_tex_cube_norm = Material(diffuse=d, specular=(0.3, 0.3, 0.3), shininess=25.0, texture=tex_cube, normals=nrm_cube)
+    mat_wall_floor = Material(diffuse=(0.424858, 0.531206, 0.8), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    root = Node.group([
+        Node.geo(Plane(), mat_wall_floor).scaled(40.0).translated((0.0, -1.0, 0.0)),
+        Node.geo(Plane(), mat_tex_plane).scaled(6.0).rotated_x(to_radians(90.0)).translated((-4.0, 2.0, -6.0)),
+        Node.geo(Cube(), mat_tex_cube).scaled(2.0).translated((-7.0, 0.0, -1.0)),
+        Node.geo(Sphere(), mat_tex_sphere).translated((-7.0, 2.0, -1.0)),
+        Node.geo(Cube(), mat_tex_cube).scaled(2.0).translated((-2.0, 0.0, 3.0)),
+        Node.geo(Sphere(), mat_tex_sphere).translated((-2.0, 2.0, 3.0)),
+        Node.geo(Plane(), mat_tex_plane_norm).scaled(6.0).rotated_x(to_radians(90.0)).translated((4.0, 2.0, -6.0)),
+        Node.geo(Cube(), mat_tex_cube_norm).scaled(2.0).translated((7.0, 0.0, -1.0)),
+        Node.geo(Sphere(), mat_tex_sphere_norm).translated((7.0, 2.0, -1.0)),
+        Node.geo(Cube(), mat_tex_cube_norm).scaled(2.0).translated((2.0, 0.0, 3.0)),
+        Node.geo(Sphere(), mat_tex_sphere_norm).translated((2.0, 2.0, 3.0)),
+    ])
+    scene = Scene(root=root, lights=[Light(position=light_pos, color=(0.9, 0.9, 0.9))], ambient=(0.2, 0.2, 0.2))
+    cam = Camera(eye=(0.0, 8.07551, 23.078941), center=(0.0, -2.854475, -16.437334), fovy_degrees=22.0)
+    return scene, cam, (910, 512)
+
+
+TEXTURED_EXAMPLES = {"normal-mapping": normal_mapping}

@@ -19,7 +19,9 @@ def description(scene: Scene) -> dict:
         args_off.append(len(args))
     d = {k: a[k] for k in ("prim_type", "prim_data", "prim_flags", "material", "child_off", "children", "root", "mesh_vert_off", "mesh_tri_off",
                             "mesh_positions", "mesh_normals", "mesh_has_normals", "mesh_indices", "n_triangles", "tri_vertices", "tri_normals",
-                            "tri_has_normals", "n_materials", "materials", "n_lights", "lights", "ambient")}
+                            "tri_has_normals", "n_materials", "materials", "n_lights", "lights", "ambient", "mesh_texcoords", "mesh_has_texcoords",
+                            "tri_texcoords", "tri_has_texcoords", "material_texture", "material_normal_map", "material_uv_trans", "n_textures",
+                            "texture_size", "texture_offset", "texture_rgb")}
     d["ops"] = ops.encode()
     d["ops_off"] = np.array(ops_off, dtype=np.uint32)
     d["args_off"] = np.array(args_off, dtype=np.uint32)

@@ -38,6 +38,9 @@ class PoScene(C.Structure):
         ("n_materials", C.c_uint32), ("materials", _dp),
         ("n_lights", C.c_uint32), ("lights", _dp),
         ("ambient", C.c_double * 3),
+        ("mesh_texcoords", _dp), ("mesh_has_texcoords", _u8p), ("tri_texcoords", _dp), ("tri_has_texcoords", _u8p),
+        ("material_texture", _ip), ("material_normal_map", _ip), ("material_uv_trans", _dp),
+        ("n_textures", C.c_uint32), ("texture_size", _up), ("texture_offset", _u64p), ("texture_rgb", _u8p),
     ]
 
 
@@ -171,6 +174,25 @@ def arrays_from_dsl(scene: Scene):
     a["materials"] = np.array([m.row() for m in lin.materials] or [[0.0] * 10], dtype=np.float64)
     a["lights"] = np.array([l.row() for l in scene.lights] or [[0.0] * 15], dtype=np.float64)
     a["ambient"] = np.array(list(map(float, scene.ambient)))
+    # textures (texture.rs), texture coordinates (mesh.rs:30, triangle.rs:18), per-material maps
+    a["mesh_texcoords"] = (np.concatenate([m.tex_coords if m.tex_coords is not None else np.zeros((len(m.positions), 2)) for m in lin.meshes])
+                           if lin.meshes else np.zeros((1, 2))).astype(np.float64)
+    a["mesh_has_texcoords"] = np.array([1 if m.tex_coords is not None else 0 for m in lin.meshes] + [0], dtype=np.uint8)
+    a["tri_texcoords"] = (np.stack([(t.tri_tex_coords if t.tri_tex_coords is not None else np.zeros((3, 2))).reshape(6) for t in lin.triangles])
+                          if nt else np.zeros((1, 6))).astype(np.float64)
+    a["tri_has_texcoords"] = np.array([1 if t.tri_tex_coords is not None else 0 for t in lin.triangles] + [0], dtype=np.uint8)
+    tid = lin.texture_index
+    a["material_texture"] = np.array([tid[id(m.texture)] if m.texture is not None else -1 for m in lin.materials] + [-1], dtype=np.int32)
+    a["material_normal_map"] = np.array([tid[id(m.normals)] if m.normals is not None else -1 for m in lin.materials] + [-1], dtype=np.int32)
+    a["material_uv_trans"] = np.array([list(map(float, m.uv_trans)) for m in lin.materials] or [[1, 0, 0, 0, 1, 0, 0, 0, 1]], dtype=np.float64)
+    a["texture_size"] = np.array([[t.pixels.shape[1], t.pixels.shape[0]] for t in lin.textures] or [[0, 0]], dtype=np.uint32)
+    offs, blob = [], []
+    for t in lin.textures:
+        offs.append(sum(len(b) for b in blob))
+        blob.append(np.ascontiguousarray(t.pixels, dtype=np.uint8).reshape(-1))
+    a["texture_offset"] = np.array(offs + [0], dtype=np.uint64)
+    a["texture_rgb"] = np.concatenate(blob) if blob else np.zeros(4, dtype=np.uint8)
+    a["n_textures"] = len(lin.textures)
     a.update(root=lin.root, n_meshes=len(lin.meshes), n_triangles=nt, n_materials=len(lin.materials), n_lights=len(scene.lights))
     return a, lin
 
@@ -195,6 +217,13 @@ def pack_arrays(a: dict, lin=None) -> PackedScene:
     s.n_materials = int(a["n_materials"]); s.materials = _p(a["materials"], _dp)
     s.n_lights = int(a["n_lights"]); s.lights = _p(a["lights"], _dp)
     s.ambient = (C.c_double * 3)(*map(float, a["ambient"]))
+    if "texture_rgb" in a:
+        s.mesh_texcoords = _p(a["mesh_texcoords"], _dp); s.mesh_has_texcoords = _p(a["mesh_has_texcoords"], _u8p)
+        s.tri_texcoords = _p(a["tri_texcoords"], _dp); s.tri_has_texcoords = _p(a["tri_has_texcoords"], _u8p)
+        s.material_texture = _p(a["material_texture"], _ip); s.material_normal_map = _p(a["material_normal_map"], _ip)
+        s.material_uv_trans = _p(a["material_uv_trans"], _dp)
+        s.n_textures = int(a["n_textures"]); s.texture_size = _p(a["texture_size"], _up)
+        s.texture_offset = _p(a["texture_offset"], _u64p); s.texture_rgb = _p(a["texture_rgb"], _u8p)
     return PackedScene(s, a, lin)
 
 

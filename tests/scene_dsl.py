@@ -39,13 +39,26 @@ def _vec3(v) -> Tuple[float, float, float]:
 
 
 @dataclass
-class Material:  # material.rs:50-86 (hot fields)
+class Texture:  # texture.rs:74-76 RgbImageBuffer: RGB8 pixels as decoded from the image file
+    pixels: np.ndarray  # (H, W, 3) uint8
+
+    @staticmethod
+    def open(path: str) -> "Texture":
+        from PIL import Image
+        return Texture(np.ascontiguousarray(np.array(Image.open(path).convert("RGB"), dtype=np.uint8)))
+
+
+@dataclass
+class Material:  # material.rs:50-86
     diffuse: Sequence[float] = (0.0, 0.0, 0.0)
     specular: Sequence[float] = (0.0, 0.0, 0.0)
     shininess: float = 0.0
     reflectivity: float = 0.0
     glossy_side_length: float = 0.0
     refraction_index: float = 0.0
+    texture: Optional["Texture"] = None      # ImageTexture (sRGB -> linear on sampling, texture.rs:162-168)
+    normals: Optional["Texture"] = None      # NormalMap (texture.rs:175-221)
+    uv_trans: Sequence[float] = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)  # row-major Mat3 (material.rs:83)
 
     def row(self) -> List[float]:
         return [*map(float, self.diffuse), *map(float, self.specular), float(self.shininess),
@@ -71,11 +84,12 @@ class MeshData:  # mesh.rs:21-34
     triangles: np.ndarray  # (m, 3) u32
     normals: Optional[np.ndarray] = None  # (n, 3) f64
     name: str = ""
+    tex_coords: Optional[np.ndarray] = None  # (n, 2) f64
 
     @staticmethod
     def load_obj(path: str) -> "MeshData":
         pos, nrm, tex = [], [], []
-        out_pos, out_nrm, tris = [], [], []
+        out_pos, out_nrm, out_tex, tris = [], [], [], []
         index_map = {}
         seen_faces = False
         with open(path, "r") as fh:
@@ -110,12 +124,15 @@ class MeshData:  # mesh.rs:21-34
                             out_pos.append(pos[v])
                             if vn >= 0:
                                 out_nrm.append(nrm[vn])
+                            if vt >= 0:
+                                out_tex.append(tex[vt])
                         corner.append(index_map[key])
                     for k in range(1, len(corner) - 1):  # fan
                         tris.append([corner[0], corner[k], corner[k + 1]])
         normals = np.array(out_nrm, dtype=np.float64) if len(out_nrm) == len(out_pos) and out_nrm else None
+        tex_coords = np.array(out_tex, dtype=np.float64) if len(out_tex) == len(out_pos) and out_tex else None
         return MeshData(np.array(out_pos, dtype=np.float64).reshape(-1, 3),
-                        np.array(tris, dtype=np.uint32).reshape(-1, 3), normals, os.path.basename(path))
+                        np.array(tris, dtype=np.uint32).reshape(-1, 3), normals, os.path.basename(path), tex_coords)
 
 
 @dataclass
@@ -125,6 +142,7 @@ class Prim:
     smooth: bool = False
     tri: Optional[np.ndarray] = None  # (3, 3) a, b, c
     tri_normals: Optional[np.ndarray] = None
+    tri_tex_coords: Optional[np.ndarray] = None  # (3, 2)
 
 
 Sphere = lambda: Prim(SPHERE)
@@ -134,9 +152,10 @@ Cylinder = lambda: Prim(CYLINDER)
 Cone = lambda: Prim(CONE)
 
 
-def Triangle(a, b, c, normals=None) -> Prim:  # triangle.rs:21-26
+def Triangle(a, b, c, normals=None, tex_coords=None) -> Prim:  # triangle.rs:8-26
     return Prim(TRIANGLE, tri=np.array([a, b, c], dtype=np.float64),
-                tri_normals=None if normals is None else np.array(normals, dtype=np.float64))
+                tri_normals=None if normals is None else np.array(normals, dtype=np.float64),
+                tri_tex_coords=None if tex_coords is None else np.array(tex_coords, dtype=np.float64))
 
 
 def Mesh(data: MeshData, smooth: bool = False) -> Prim:  # mesh.rs:131-144
@@ -238,12 +257,13 @@ class Linearised:
     meshes: List[MeshData] = field(default_factory=list)
     triangles: List[Prim] = field(default_factory=list)
     materials: List[Material] = field(default_factory=list)
+    textures: List[Texture] = field(default_factory=list)
     root: int = 0
 
 
 def linearise(scene: Scene) -> Linearised:
     lin = Linearised()
-    node_id, mesh_id, mat_id = {}, {}, {}
+    node_id, mesh_id, mat_id, tex_id = {}, {}, {}, {}
     order: List[Node] = []
 
     def visit(n: Node):
@@ -267,6 +287,10 @@ def linearise(scene: Scene) -> Linearised:
             if id(mat) not in mat_id:
                 mat_id[id(mat)] = len(lin.materials)
                 lin.materials.append(mat)
+                for t in (mat.texture, mat.normals):
+                    if t is not None and id(t) not in tex_id:
+                        tex_id[id(t)] = len(lin.textures)
+                        lin.textures.append(t)
             data = 0
             if prim.kind in (MESH, KDMESH):
                 if id(prim.mesh) not in mesh_id:
@@ -281,4 +305,5 @@ def linearise(scene: Scene) -> Linearised:
         for c in n.children:
             lin.children.append(node_id[id(c)])
         lin.child_off.append(len(lin.children))
+    lin.texture_index = tex_id
     return lin

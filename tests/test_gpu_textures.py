@@ -1,0 +1,118 @@
+"""Image textures and normal maps (src/texture.rs, consumed at material.rs:109-144) on
+the GPU against the oracle and the reference's golden render of examples/normal-mapping.rs."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import host_glue
+from example_scenes import load_mesh, normal_mapping
+from scene_dsl import (GOLDEN, Camera, Cube, Cylinder, Light, Material, Mesh, Node, Plane, Scene, Sphere, Texture, Triangle, default_background,
+                       to_radians)
+
+pytestmark = pytest.mark.gpu
+
+
+def ulp_diff(a, b):
+    return np.abs(np.ascontiguousarray(a, dtype=np.float64).view(np.int64) - np.ascontiguousarray(b, dtype=np.float64).view(np.int64))
+
+
+@pytest.fixture(scope="module")
+def H():
+    from portrayer_amd import _hip
+    return _hip
+
+
+@pytest.fixture(scope="module")
+def host():
+    from portrayer_amd import host
+    return host
+
+
+def block_means(a, k=8):
+    h, w, _ = a.shape
+    h2, w2 = h // k * k, w // k * k
+    return a[:h2, :w2].astype(float).reshape(h2 // k, k, w2 // k, k, 3).mean(axis=(1, 3))
+
+
+@pytest.mark.parametrize("mode", ["flat", "kd"])
+def test_normal_mapping_example_matches_oracle(oracle, host, H, mode):
+    scene, cam, _ = normal_mapping()
+    w, h = 455, 256
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_KD if mode == "kd" else H.TRAVERSE_FLAT)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), stats=True)
+    ref = oracle.render(scene, cam, w, h, mode=oracle.MODE_KD if mode == "kd" else oracle.MODE_FLAT)
+    assert st["hits"] == ref.stats["hits"] and st["shadow"] == ref.stats["shadow"]
+    bad = (rgb != ref.rgb).any(axis=2)
+    # sphere texture coordinates go through atan2 / acos (sphere.rs:57-60): a last-bit difference between
+    # the device and glibc can move a sample across a texel boundary; everything else must be identical
+    assert bad.sum() <= 2, f"{bad.sum()} pixels differ"
+    assert ulp_diff(linear, ref.linear)[~bad].max() <= 64
+
+
+def test_gpu_normal_mapping_vs_reference_golden(host, H):
+    """render/04a_normal-mapping.png was rendered with many jittered samples from JPEG textures decoded by
+    another decoder: compare 8x8 block means of a centre-sample GPU render (measured on the oracle: mean
+    1.1 levels, 3 % of blocks above 6, all on the top edge of the left wall)."""
+    scene, cam, (w, h) = normal_mapping()
+    g = np.array(Image.open(os.path.join(GOLDEN, "render", "04a_normal-mapping.png")).convert("RGB"))
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_FLAT)
+    rgb, _, _ = r.render(host_glue.cam10(cam), w, h, default_background(w, h), want_linear=False)
+    d = np.abs(block_means(rgb) - block_means(g)).max(axis=2)
+    assert d.mean() < 1.5 and (d > 6).mean() < 0.05
+
+
+def textured_scene(seed):
+    rng = np.random.default_rng(seed)
+    tex_a = Texture(rng.integers(0, 256, (37, 53, 3), dtype=np.uint8))
+    tex_b = Texture(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8))
+    nm = rng.integers(0, 256, (48, 32, 3), dtype=np.uint8); nm[..., 2] = np.maximum(nm[..., 2], 140)  # normals pointing out of the surface
+    nmap = Texture(nm)
+    m_cube = Material(diffuse=(0.5, 0.5, 0.5), specular=(0.4, 0.4, 0.4), shininess=30.0, texture=tex_a, normals=nmap)
+    m_sphere = Material(diffuse=(0.2, 0.8, 0.2), specular=(0.5, 0.5, 0.5), shininess=10.0, texture=tex_b, reflectivity=0.4,
+                        uv_trans=(2.0, 0.0, 0.25, 0.0, 3.0, -0.5, 0.0, 0.0, 1.0))
+    m_plane = Material(diffuse=(0.9, 0.9, 0.9), texture=tex_a, uv_trans=(4.0, 0.0, 0.0, 0.0, 4.0, 0.0, 0.0, 0.0, 1.0))
+    m_tri = Material(diffuse=(1, 1, 1), specular=(0.3, 0.3, 0.3), shininess=5.0, texture=tex_b, normals=nmap)
+    m_mesh = Material(diffuse=(1, 1, 1), specular=(0.2, 0.2, 0.2), shininess=50.0, texture=tex_b)
+    m_plain = Material(diffuse=(0.8, 0.3, 0.3), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    monkey = load_mesh("monkey.obj")  # has vt records
+    assert monkey.tex_coords is not None
+    tri = Triangle((-1.5, 0.0, 0.0), (1.5, 0.0, 0.0), (0.0, 2.0, 0.5), normals=rng.uniform(-1, 1, (3, 3)) + np.array([0, 0, 2.0]),
+                   tex_coords=[(0.0, 0.0), (1.0, 0.1), (0.4, 1.3)])
+    root = Node.group([
+        Node.geo(Plane(), m_plane).scaled(14.0).translated((0.0, -1.0, 0.0)),
+        Node.geo(Cube(), m_cube).scaled((1.5, 2.0, 1.0)).rotated_y(0.5).translated((-3.0, 0.0, 0.0)),
+        Node.geo(Sphere(), m_sphere).scaled(1.2).rotated_xzy((0.3, 0.9, -0.4)).translated((0.0, 0.3, 0.5)),
+        Node.geo(tri, m_tri).translated((3.0, -0.8, 0.0)),
+        Node.geo(Mesh(monkey, smooth=bool(seed % 2)), m_mesh).rotated_y(to_radians(150.0 + 20 * seed)).translated((0.5, 2.3, -1.0)),
+        Node.geo(Cylinder(), m_plain).translated((-1.2, -0.5, 2.0)),
+    ])
+    lights = [Light(position=(4.0, 7.0, 8.0), color=(0.8, 0.8, 0.8)), Light(position=(-6.0, 5.0, 3.0), color=(0.3, 0.3, 0.5))]
+    return Scene(root=root, lights=lights, ambient=(0.25, 0.25, 0.25)), Camera(eye=(0.5, 3.0, 10.0), center=(0.0, 0.5, 0.0), fovy_degrees=38.0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("mode", ["flat", "kd"])
+def test_random_textured_scene_matches_oracle(oracle, host, H, seed, mode):
+    scene, cam = textured_scene(seed)
+    w, h = 160, 110
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_KD if mode == "kd" else H.TRAVERSE_FLAT, kd_depth=5)
+    kw = dict(samples=2, seed=seed, sample_mode=H.SAMPLE_RNG) if seed else {}
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), stats=True, **kw)
+    okw = dict(samples=2, seed=seed, jitter=oracle.JITTER_RNG) if seed else {}
+    ref = oracle.render(scene, cam, w, h, mode=oracle.MODE_KD if mode == "kd" else oracle.MODE_FLAT, kd_depth=5, **okw)
+    for k in ("primary", "shadow", "reflect", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert ref.stats["kd_plane_miss"] == 0
+    bad = (rgb != ref.rgb).any(axis=2)
+    assert bad.sum() <= 2, f"{bad.sum()} pixels differ, first at {np.argwhere(bad)[:3]}"
+    assert ulp_diff(linear, ref.linear)[~bad].max() <= 4096
+
+
+def test_texture_on_primitive_without_uv_is_rejected(host, H):
+    """material.rs:133 / :141: 'Texture mapping is not supported for this primitive!' (a panic in the reference)."""
+    tex = Texture(np.zeros((4, 4, 3), dtype=np.uint8))
+    scene = Scene(root=Node.group([Node.geo(Cylinder(), Material(diffuse=(1, 1, 1), texture=tex))]), lights=[], ambient=(1, 1, 1))
+    with pytest.raises(host.PortrayerHostError):
+        host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_FLAT)

@@ -125,3 +125,27 @@ def test_kd_tree_shape_big_scene(oracle):  # SURVEY App.C: depth 10 -> 1023 spli
     assert (kinds == 0).sum() == 1023 and (kinds == 1).sum() == 1024
     assert len(tree["items"]) == 6806
     assert tree["count"][kinds == 1].max() == 12
+
+
+def test_textured_golden_normal_mapping(oracle):
+    """render/04a_normal-mapping.png pins the texture path (uv / TBN of Plane, Cube, Sphere; nearest-texel
+    sampling; sRGB -> linear; normal maps, texture.rs + material.rs:109-144). The golden was rendered with
+    many jittered samples and another JPEG decoder, so 8x8 block means are compared."""
+    from example_scenes import normal_mapping
+    scene, cam, (w, h) = normal_mapping()
+    g = golden("04a_normal-mapping.png")
+    r = oracle.render(scene, cam, w, h, mode=oracle.MODE_HIER)
+
+    def blk(a, k=8):
+        hh, ww = a.shape[0] // k * k, a.shape[1] // k * k
+        return a[:hh, :ww].astype(float).reshape(hh // k, k, ww // k, k, 3).mean(axis=(1, 3))
+
+    d = np.abs(blk(r.rgb) - blk(g)).max(axis=2)
+    assert d.mean() < 1.5 and (d > 6).mean() < 0.05  # measured 1.11 / 3.1 %
+    # a wrong orientation of the maps is far outside that band: flip v of every texture and look again
+    textures = {id(n.geometry[1].texture): n.geometry[1].texture for n in scene.root.children if n.geometry[1].texture is not None}
+    for t in textures.values():
+        t.pixels = np.ascontiguousarray(t.pixels[::-1])
+    r2 = oracle.render(scene, cam, w, h, mode=oracle.MODE_HIER)
+    d2 = np.abs(blk(r2.rgb) - blk(g)).max(axis=2)
+    assert d2.mean() > 1.5 * d.mean()
