@@ -37,6 +37,9 @@ WORKLOADS = {
     "cows": ("macho-cows", 0, 1280, 720, 16),
     "primitives": ("primitives-simple", 0, 800, 600, 1),
     "triangle": ("single-triangle", 0, 256, 256, 1),
+    # synthetic, not reference scenes: the big-scene generator over cow.obj instances / baked triangles
+    "big-mesh": ("synthetic:big-mesh", 6, 1920, 1080, 16),
+    "big-soup": ("synthetic:big-soup", 6, 1920, 1080, 16),
 }
 
 
@@ -110,7 +113,14 @@ def main():
     example, n, w, h, s = WORKLOADS[args.workload]
     w, h, s = args.width or w, args.height or h, args.samples or s
     device = 0 if args.same_device else local_rank
-    scene = host.Scene.example(example, n=n or 10)
+    if example.startswith("synthetic:"):
+        import example_scenes
+        import host_glue
+        dsl_scene, dsl_cam, _ = example_scenes.SYNTHETIC[example.split(":")[1]](n)
+        scene = host_glue.host_scene(dsl_scene)
+        scene.camera = host_glue.cam10(dsl_cam)
+    else:
+        scene = host.Scene.example(example, n=n or 10)
     traverse = H.TRAVERSE_KD if args.traversal == "kd" else H.TRAVERSE_FLAT
     renderer = host.Renderer(scene, traverse, kd_depth=10, device=device)  # flatten + build + upload: once, outside the timed region
     ctx = renderer.context
@@ -250,7 +260,7 @@ def main():
             img = np.zeros((h, w, 3), dtype=np.uint8)
             _, _, hst = renderer.render(scene.camera, w, h, bg, samples=s, seed=0, sample_mode=H.SAMPLE_RNG, into=img, want_linear=False)
             out["config"]["host_buffer_path"] = {"ms_per_frame": hst["total_ms"], "Mray_per_s": rays_frame / hst["total_ms"] / 1e3}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not example.startswith("synthetic:"):
             out["cpu_baseline"] = cpu_baseline(example, n, w, h, args.traversal)
     else:
         out = None

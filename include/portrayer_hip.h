@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 /* enum Primitive, src/primitive.rs:67-81 */
 enum { PT_PRIM_SPHERE = 0, PT_PRIM_TRIANGLE = 1, PT_PRIM_MESH = 2, PT_PRIM_KDMESH = 3, PT_PRIM_PLANE = 4, PT_PRIM_CUBE = 5, PT_PRIM_CYLINDER = 6, PT_PRIM_CONE = 7 };
@@ -100,6 +100,19 @@ typedef struct {
     const uint32_t *texture_size;       /* n_textures x 2: width, height                                   */
     const uint64_t *texture_offset;     /* n_textures: byte offset of texel (0,0) in texture_rgb           */
     const uint8_t *texture_rgb;         /* all texels, row-major RGB8                                      */
+    /* KDMesh triangle trees (ABI 3): KDMesh::new builds a k-d tree over the mesh's triangles
+     * (src/kdtree/kdmesh.rs:37-58, KD_MESH_DEPTH) whose traversal can miss hits a Mesh finds (squared
+     * extent, bounding_box.rs:95-99); to reproduce that the host passes the trees, linearised like
+     * pt_kdtree with node indices into the shared kdm_* arrays. Optional: a KDMesh whose mesh has
+     * mesh_kd_root < 0 (or NULL arrays) is traversed like a Mesh. */
+    const int32_t *mesh_kd_root;        /* n_meshes: root node index in kdm_*, or -1                       */
+    const int32_t *mesh_kd_depth;       /* n_meshes: Split levels above the deepest leaf                   */
+    const double *mesh_kd_bounds;       /* n_meshes x 6: root bounds min, max                              */
+    const double *mesh_kd_bounds_invtrans; /* n_meshes x 16: BoundingBox::invtrans of the root bounds      */
+    uint32_t n_kdm_nodes;
+    const int32_t *kdm_axis; const double *kdm_plane; const int32_t *kdm_front, *kdm_back, *kdm_first, *kdm_count;
+    uint32_t n_kdm_items;
+    const int32_t *kdm_items;           /* triangle indices local to the mesh, in leaf Vec order            */
 } pt_scene;
 
 /* The scene k-d tree the host built (KDTreeScene::from, src/kdtree/kdscene.rs:19-43), linearised;

@@ -40,6 +40,9 @@ class PtScene(C.Structure):
         ("mesh_texcoords", _dp), ("mesh_has_texcoords", _u8p), ("tri_texcoords", _dp), ("tri_has_texcoords", _u8p),
         ("material_texture", _ip), ("material_normal_map", _ip), ("material_uv_trans", _dp),
         ("n_textures", C.c_uint32), ("texture_size", _up), ("texture_offset", _u64p), ("texture_rgb", _u8p),
+        ("mesh_kd_root", _ip), ("mesh_kd_depth", _ip), ("mesh_kd_bounds", _dp), ("mesh_kd_bounds_invtrans", _dp),
+        ("n_kdm_nodes", C.c_uint32), ("kdm_axis", _ip), ("kdm_plane", _dp), ("kdm_front", _ip), ("kdm_back", _ip), ("kdm_first", _ip), ("kdm_count", _ip),
+        ("n_kdm_items", C.c_uint32), ("kdm_items", _ip),
     ]
 
 

@@ -197,7 +197,7 @@ struct pt_context {
     int n_cu = 0;
     std::string err;
     PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh_items, kd, kd_items;
-    PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv;
+    PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, mkd, mkd_items;
     PtBuf frames, accum, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
     PtSceneView view;
     bool have_scene = false;
@@ -262,7 +262,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc};
+                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -363,9 +363,58 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         for (int r = 0; r < 12; r++) mi.bbox_inv[r] = s->mesh_bounds_invtrans ? s->mesh_bounds_invtrans[16 * (size_t)m + r] : 0.0;
         if (!s->mesh_bounds_invtrans) return pt_fail(c, PT_ERR_ARGUMENT, "mesh_bounds_invtrans missing");
         mi.tri_first = (uint32_t)t0; mi.tri_count = (uint32_t)(t1 - t0);
-        mi.blas_root = ref.child; mi.pad = 0;
+        mi.blas_root = ref.child; mi.kd_root = -1; mi.kd_extent = 0.0;
+        for (int r = 0; r < 12; r++) mi.kd_bbox_inv[r] = 0.0;
         for (int k = 0; k < 3; k++) { mb.lo[k] -= 1e-5 * ext; mb.hi[k] += 1e-5 * ext; }
         mesh_box[m] = mb;
+    }
+    // ---- KDMesh triangle trees (reference structure)
+    std::vector<PtKdNode> mkd;
+    std::vector<uint32_t> mkd_items;
+    int max_kdm_depth = 0;
+    if (s->mesh_kd_root && s->n_kdm_nodes) {
+        if (!s->kdm_axis || !s->kdm_plane || !s->kdm_front || !s->kdm_back || !s->kdm_first || !s->kdm_count || (s->n_kdm_items && !s->kdm_items) ||
+            !s->mesh_kd_bounds || !s->mesh_kd_bounds_invtrans)
+            return pt_fail(c, PT_ERR_ARGUMENT, "incomplete KDMesh tree arrays");
+        mkd.resize(s->n_kdm_nodes);
+        for (uint32_t i = 0; i < s->n_kdm_nodes; i++) {
+            PtKdNode& k = mkd[i];
+            k.axis = s->kdm_axis[i]; k.plane = s->kdm_plane[i]; k.front = s->kdm_front[i]; k.back = s->kdm_back[i];
+            k.first = s->kdm_first[i]; k.count = s->kdm_count[i]; k.pad = 0;
+            if (k.axis >= 0) {
+                if (k.axis > 2 || k.front < 0 || k.back < 0 || (uint32_t)k.front >= s->n_kdm_nodes || (uint32_t)k.back >= s->n_kdm_nodes)
+                    return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh tree child out of range");
+            } else if (k.first < 0 || k.count < 0 || (uint32_t)(k.first + k.count) > s->n_kdm_items) {
+                return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh leaf range out of bounds");
+            }
+        }
+        mkd_items.assign(s->n_kdm_items, 0);
+        // leaf items are local triangle indices: make them global, mesh by mesh (a leaf belongs to the mesh whose tree reaches it)
+        std::vector<int32_t> owner(s->n_kdm_nodes, -1);
+        for (uint32_t m = 0; m < s->n_meshes; m++) {
+            int32_t root = s->mesh_kd_root[m];
+            if (root < 0) continue;
+            if ((uint32_t)root >= s->n_kdm_nodes) return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh root out of range");
+            std::vector<int32_t> todo{root};
+            while (!todo.empty()) {
+                int32_t i = todo.back(); todo.pop_back();
+                if (owner[i] >= 0) return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh trees must not share nodes");
+                owner[i] = (int32_t)m;
+                if (mkd[i].axis >= 0) { todo.push_back(mkd[i].front); todo.push_back(mkd[i].back); }
+                else for (int32_t k = 0; k < mkd[i].count; k++) {
+                    int32_t local = s->kdm_items[mkd[i].first + k];
+                    if (local < 0 || (uint64_t)local >= s->mesh_tri_off[m + 1] - s->mesh_tri_off[m]) return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh leaf triangle out of range");
+                    mkd_items[mkd[i].first + k] = (uint32_t)(s->mesh_tri_off[m] + (uint64_t)local);
+                }
+            }
+            PtMeshInfo& mi = meshes[m];
+            mi.kd_root = root;
+            const double* b = s->mesh_kd_bounds + 6 * (size_t)m;
+            double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+            mi.kd_extent = (dx * dx + dy * dy) + dz * dz;  // bounding_box.rs:95-99
+            for (int r = 0; r < 12; r++) mi.kd_bbox_inv[r] = s->mesh_kd_bounds_invtrans[16 * (size_t)m + r];
+            max_kdm_depth = std::max(max_kdm_depth, s->mesh_kd_depth ? std::max(s->mesh_kd_depth[m], 0) : 24);
+        }
     }
     for (uint32_t t = 0; t < s->n_triangles; t++)
         for (int k = 0; k < 9; k++) {
@@ -464,7 +513,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     if ((rc = pt_upload(c, c->inv, inv)) || (rc = pt_upload(c, c->fwd, fwd)) || (rc = pt_upload(c, c->nrm, nrm)) ||
         (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_v, tri_v)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
         (rc = pt_upload(c, c->meshes, meshes)) || (rc = pt_upload(c, c->bvh, bvh)) || (rc = pt_upload(c, c->bvh_items, items)) ||
-        (rc = pt_upload(c, c->kd, kdn)) || (rc = pt_upload(c, c->kd_items, kdi)))
+        (rc = pt_upload(c, c->kd, kdn)) || (rc = pt_upload(c, c->kd_items, kdi)) || (rc = pt_upload(c, c->mkd, mkd)) ||
+        (rc = pt_upload(c, c->mkd_items, mkd_items)))
         return rc;
     std::vector<double> mats(s->materials, s->materials + 10 * (size_t)s->n_materials);
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
@@ -542,14 +592,16 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.tlas_root = tlas.child; v.pad0 = 0;
     v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
     v.kd_extent = kd_extent;
+    v.mkd = (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;
     v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : PT_MODE_FLAT);
-    int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + max_blas_depth + 2 : tlas.depth + max_blas_depth + 4;
+    int below = std::max(max_blas_depth, 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
+    int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + below + 2 : tlas.depth + below + 4;
     v.stack_cap = std::max(cap, 8);
     if (textured) {
         v.mat_maps = (const int32_t*)c->mat_maps.p; v.uv_trans = (const double*)c->uv_trans.p; v.tex = (const PtTexInfo*)c->tex.p;
         v.tex_rgb = (const uint8_t*)c->tex_rgb.p; v.srgb_lut = (const double*)c->srgb_lut.p; v.tri_uv = (const double*)c->tri_uv.p;
     }
-    if ((size_t)v.stack_cap * PT_BLOCK * 4 > 64 * 1024) return pt_fail(c, PT_ERR_SCENE, "traversal stack would not fit in LDS (tree too deep)");
+    if ((size_t)v.stack_cap * PT_BLOCK * 4 > 150 * 1024) return pt_fail(c, PT_ERR_SCENE, "traversal stack would not fit in LDS (tree too deep)");
     c->have_scene = true;
     return PT_OK;
 }
@@ -591,6 +643,10 @@ static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream,
     uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
     *grid_out = grid;
     if (!launch) return hipSuccess;
+    if (lds > 64 * 1024) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
     return hipGetLastError();
 }
@@ -860,6 +916,11 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     PT_HIP(c, hipMemcpy(d_d, directions, n * 24, hipMemcpyHostToDevice));
     size_t lds = (size_t)c->view.stack_cap * PT_BLOCK * 4;
     dim3 grid((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK));
+    if (lds > 64 * 1024) {
+        const void* f = c->view.mode == PT_MODE_FLAT_NOMESH ? reinterpret_cast<const void*>(&pt_cast_kernel<PT_MODE_FLAT_NOMESH>)
+                        : (c->view.mode == PT_MODE_KD ? reinterpret_cast<const void*>(&pt_cast_kernel<PT_MODE_KD>) : reinterpret_cast<const void*>(&pt_cast_kernel<PT_MODE_FLAT>));
+        PT_HIP(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (c->view.mode == PT_MODE_FLAT_NOMESH) hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_FLAT_NOMESH>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
     else if (c->view.mode == PT_MODE_KD) hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_KD>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
     else hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_FLAT>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);

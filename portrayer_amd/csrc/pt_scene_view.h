@@ -47,7 +47,9 @@ struct PtMeshInfo {
     double bbox_inv[12];   // rows 0..2 of BoundingBox::invtrans (bounding_box.rs:55-82)
     uint32_t tri_first, tri_count;
     uint32_t blas_root;    // encoded like PtBvhNode::child0 (may be a leaf, or PT_REF_EMPTY)
-    uint32_t pad;
+    int32_t kd_root;       // KDMesh: root of the mesh's own k-d tree in mkd[] (kdmesh.rs:37-58), or -1
+    double kd_extent;      // squared diagonal of that tree's root bounds (node.rs:62-64)
+    double kd_bbox_inv[12];  // BoundingBox::invtrans of the root bounds (kdmesh.rs:66-68)
 };
 
 struct PtTexInfo {  // one RgbImageBuffer (texture.rs:74-76) inside tex_rgb
@@ -82,6 +84,9 @@ struct PtSceneView {
     const uint8_t* tex_rgb;    // RGB8 texels of all textures
     const double* srgb_lut;    // 256 entries: (k / 255)^2.2 computed on the host (texture.rs:162-168)
     const double* tri_uv;      // n_tris x 6: texture coordinates of a, b, c (mesh.rs:30, triangle.rs:18)
+    // KDMesh triangle trees, the reference's structure (kdtree/kdmesh.rs); items are global triangle indices
+    const PtKdNode* mkd;
+    const uint32_t* mkd_items;
 };
 
 struct PtCamera {  // camera.rs:17-31, built on the host (look_at inverse, tan)

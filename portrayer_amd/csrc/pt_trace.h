@@ -128,6 +128,63 @@ PT_HD double pt_cand_end(const PtHit& best, uint32_t node, uint32_t sub) {
     return before ? pt_next_up(best.t) : best.t;
 }
 
+PT_HD double pt_axis(PtVec3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+// KDMesh::ray_hit (kdtree/kdmesh.rs:62-74): box test on the tree's root bounds, then the mesh's OWN
+// k-d tree of triangles walked exactly like the scene tree (node.rs:33-51 + :66-203): front to back,
+// range clipped at straddled planes, the first leaf with a hit wins, and — quirk Q3 — the segment used
+// to classify sides ends at start + extent (squared diagonal), so hits farther away than that can be
+// missed. Reproduced because results differ from Mesh whenever the quirk bites.
+template <bool STATS>
+PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay& local, double start, double end, const PtStack& stk,
+                         int sp0, double* t_out, uint32_t* tri_out, PtCounters* cnt) {
+    if (STATS) cnt->n_bbox++;
+    if (!pt_bbox_test_hit(m.kd_bbox_inv, local, start, end)) return false;
+    int sp = sp0;
+    int32_t cur = m.kd_root;
+    const double extent = m.kd_extent;
+    const double end0 = end;  // a pending far side's range end = the start of the entry below it, or end0
+    for (;;) {
+        const PtKdNode n = sc.mkd[cur];
+        if (n.axis < 0) {  // leaf: [T]::ray_hit (ray.rs:50-63) over the leaf's triangles, in order, strict shrinking end
+            if (STATS) cnt->n_leaf++;
+            bool found = false;
+            double e = end;
+            for (int32_t i = 0; i < n.count; i++) {
+                uint32_t tri = sc.mkd_items[n.first + i];
+                double tt, beta, gamma;
+                if (STATS) cnt->n_tri++;
+                if (pt_triangle_hit(sc.tri_v + 9 * (size_t)tri, local, start, e, &tt, &beta, &gamma)) { e = tt; *t_out = tt; *tri_out = tri; found = true; }
+            }
+            if (found) return true;
+        } else {
+            if (STATS) cnt->n_inner++;
+            double t_max = start + extent;
+            if (!pt_in_range(start, end, t_max)) t_max = end - PT_EPSILON;
+            double t_min = start + PT_EPSILON;
+            double o = pt_axis(local.o, n.axis), d = pt_axis(local.d, n.axis);
+            bool s = ((o + d * t_min) - n.plane) >= 0.0;
+            bool e = ((o + d * t_max) - n.plane) >= 0.0;
+            if (s == e) { cur = s ? n.front : n.back; continue; }
+            double plane_t = (n.plane - o) / d;
+            if (pt_in_range(start, end, plane_t)) {
+                if (sp + 3 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
+                pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));  // pending far side: (node, start = plane_t)
+                pt_push_f64(stk, sp, plane_t);
+                cur = s ? n.front : n.back;
+                end = plane_t;
+                continue;
+            }
+            if (STATS) cnt->kd_plane_miss++;  // node.rs:146-147 / :177-178 would panic
+        }
+        if (sp == sp0) return false;
+        start = pt_pop_f64(stk, sp);
+        cur = (int32_t)pt_pop(stk, sp);
+        if (sp == sp0) end = end0;
+        else { int peek = sp; end = pt_pop_f64(stk, peek); }
+    }
+}
+
 // flat_scene.rs:71-99 for one flattened node: transform the ray into model space, dispatch on the
 // primitive (primitive.rs:55-62), keep the hit if it beats `best`. Returns true if best changed.
 template <bool STATS>
@@ -153,6 +210,12 @@ PT_HD bool pt_test_node(const PtSceneView& sc, uint32_t node, const PtRay& ray, 
     }
     default: {  // PT_MESH / PT_KDMESH: mesh.rs:146-167 (box test, then the nearest triangle)
         const PtMeshInfo& m = sc.meshes[data];
+        if (type == PT_KDMESH && m.kd_root >= 0) {
+            uint32_t tri = 0;
+            if (!pt_kdmesh_hit<STATS>(sc, m, local, start, pt_cand_end(best, node, 0), stk, sp, &t, &tri, cnt)) return false;
+            best.t = t; best.node = node; best.sub = tri;
+            return true;
+        }
         if (STATS) cnt->n_bbox++;
         if (!pt_bbox_test_hit(m.bbox_inv, local, start, pt_cand_end(best, node, 0))) return false;
         bool changed = false;
@@ -260,7 +323,13 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                 uint32_t type = info[0], data = info[1];
                 PtRay lr = pt_ray_to_local(sc.inv + 12 * (size_t)item, ray);  // flat_scene.rs:74
                 if (STATS) cnt->n_analytic++;
-                if (MESH && (type == PT_MESH || type == PT_KDMESH)) {  // mesh.rs:146-155: box test, then the triangles
+                if (MESH && type == PT_KDMESH && sc.meshes[data].kd_root >= 0) {  // the reference's own triangle tree (quirk Q3)
+                    double t; uint32_t tri = 0;
+                    if (pt_kdmesh_hit<STATS>(sc, sc.meshes[data], lr, PT_EPSILON, pt_cand_end(best, item, 0), stk, sp, &t, &tri, cnt)) {
+                        best.t = t; best.node = item; best.sub = tri;
+                        if (any) return true;
+                    }
+                } else if (MESH && (type == PT_MESH || type == PT_KDMESH)) {  // mesh.rs:146-155: box test, then the triangles
                     const PtMeshInfo& m = sc.meshes[data];
                     if (STATS) cnt->n_bbox++;
                     if (m.blas_root == PT_REF_EMPTY || !pt_bbox_test_hit(m.bbox_inv, lr, PT_EPSILON, pt_cand_end(best, item, 0))) continue;
@@ -298,8 +367,6 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
         }
     }
 }
-
-PT_HD double pt_axis(PtVec3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
 // KD mode: kdtree/node.rs:112-202. A pending far side is (node, start) = 3 words: its range end is
 // the start of the entry below it on the stack (or +inf), because the current `end` always equals

@@ -527,6 +527,41 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
         const double* im = &bb.invtrans.m[0][0];
         mesh_bounds_inv.insert(mesh_bounds_inv.end(), im, im + 16);
     }
+    // KDMesh::new (kdmesh.rs:37-58): a k-d tree over the triangles of every mesh a KDMesh primitive uses
+    std::vector<int32_t> mesh_kd_root(meshes.size(), -1), mesh_kd_depth(meshes.size(), 0);
+    std::vector<double> mesh_kd_bounds(6 * meshes.size(), 0.0), mesh_kd_bounds_inv(16 * meshes.size(), 0.0);
+    std::vector<int32_t> kdm_axis, kdm_front, kdm_back, kdm_first, kdm_count, kdm_items;
+    std::vector<double> kdm_plane;
+    {
+        long kd_mesh_depth = 10;  // env KD_MESH_DEPTH, kdmesh.rs:51-53
+        if (const char* e = std::getenv("KD_MESH_DEPTH")) { char* end = nullptr; long v = std::strtol(e, &end, 10); if (end && *end == 0 && v >= 0) kd_mesh_depth = v; }
+        for (size_t i = 0; i < n; i++) {
+            const auto& p = flat_.root[i].geometry.primitive;
+            if (p.kind != primitive::Primitive::KDMeshK) continue;
+            size_t mi = (size_t)mesh_id[p.mesh.get()];
+            if (mesh_kd_root[mi] >= 0) continue;
+            const auto& pos = p.mesh->positions();
+            std::vector<BoundingBox> tb;
+            tb.reserve(p.mesh->triangles().size());
+            for (const auto& t : p.mesh->triangles()) {  // triangle.rs:29-36
+                Vec3 a = pos[t[0]], b = pos[t[1]], c = pos[t[2]];
+                tb.push_back(BoundingBox::create(Vec3::partial_min(a, Vec3::partial_min(b, c)), Vec3::partial_max(a, Vec3::partial_max(b, c))));
+            }
+            KdTree t = kd_partition(tb, (size_t)kd_mesh_depth, PartitionConfig{3, 3, 10});
+            int32_t base = (int32_t)kdm_axis.size(), ibase = (int32_t)kdm_items.size();
+            for (size_t k = 0; k < t.axis.size(); k++) {
+                kdm_axis.push_back(t.axis[k]); kdm_plane.push_back(t.plane[k]);
+                kdm_front.push_back(t.axis[k] >= 0 ? t.front[k] + base : -1); kdm_back.push_back(t.axis[k] >= 0 ? t.back[k] + base : -1);
+                kdm_first.push_back(t.axis[k] < 0 ? t.first[k] + ibase : 0); kdm_count.push_back(t.count[k]);
+            }
+            kdm_items.insert(kdm_items.end(), t.items.begin(), t.items.end());
+            mesh_kd_root[mi] = base; mesh_kd_depth[mi] = t.max_depth;
+            const double b6[6] = {t.root_min.x, t.root_min.y, t.root_min.z, t.root_max.x, t.root_max.y, t.root_max.z};
+            std::memcpy(&mesh_kd_bounds[6 * mi], b6, sizeof b6);
+            BoundingBox rb = BoundingBox::create(t.root_min, t.root_max);  // kdmesh.rs:26-30 bounds(): the root node's bounds
+            std::memcpy(&mesh_kd_bounds_inv[16 * mi], rb.invtrans.m, 128);
+        }
+    }
     std::vector<double> lights;
     for (const auto& l : flat_.lights) {
         const double row[15] = {l.position.x, l.position.y, l.position.z, l.color.r, l.color.g, l.color.b, l.falloff.c0, l.falloff.c1, l.falloff.c2,
@@ -547,6 +582,14 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
     s.n_materials = (uint32_t)(materials.size() / 10); s.materials = materials.data();
     s.n_lights = (uint32_t)flat_.lights.size(); s.lights = lights.data();
     s.ambient[0] = flat_.ambient.r; s.ambient[1] = flat_.ambient.g; s.ambient[2] = flat_.ambient.b;
+    if (!kdm_axis.empty()) {
+        s.mesh_kd_root = mesh_kd_root.data(); s.mesh_kd_depth = mesh_kd_depth.data();
+        s.mesh_kd_bounds = mesh_kd_bounds.data(); s.mesh_kd_bounds_invtrans = mesh_kd_bounds_inv.data();
+        s.n_kdm_nodes = (uint32_t)kdm_axis.size();
+        s.kdm_axis = kdm_axis.data(); s.kdm_plane = kdm_plane.data(); s.kdm_front = kdm_front.data(); s.kdm_back = kdm_back.data();
+        s.kdm_first = kdm_first.data(); s.kdm_count = kdm_count.data();
+        s.n_kdm_items = (uint32_t)kdm_items.size(); s.kdm_items = kdm_items.data();
+    }
     std::vector<uint32_t> tex_size;
     std::vector<uint64_t> tex_off;
     std::vector<uint8_t> tex_rgb;

@@ -189,3 +189,37 @@ def normal_mapping(light_pos=(0.0, 8.0, 10.0)):
 
 
 TEXTURED_EXAMPLES = {"normal-mapping": normal_mapping}
+
+
+def big_mesh(n: int = 6):
+    """SURVEY §8(d) synthetic variant "big-mesh-N": the big-scene generator with the primitive list
+    replaced by Mesh(cow.obj): n = 6 -> 216 instances = 1,253,664 instanced triangles (one 5,804-triangle
+    mesh, 216 transforms). Not a reference scene."""
+    cow = load_mesh("cow.obj")
+    scene, cam, size = big_scene(n, prims=[lambda: Mesh(cow)])
+    # cow.obj spans about 5 units; the generator scales by 30..60, far larger than the grid pitch: shrink
+    for node in scene.root.children:
+        node.ops[0] = ("s", tuple(v / 4.0 for v in node.ops[0][1]))
+    return scene, cam, size
+
+
+def big_soup(n: int = 6):
+    """SURVEY §8(d) synthetic variant "big-soup": the same instances baked to ONE world-space triangle
+    mesh (n = 6: 1,253,664 triangles, 90 MB of vertex records) — the input where the scene no longer fits
+    the caches. Not a reference scene."""
+    import oracle_lib as O
+    scene, cam, size = big_mesh(n)
+    cow = load_mesh("cow.obj")
+    pos, tris = [], []
+    for k, node in enumerate(scene.root.children):
+        m = O.compose(node.ops)
+        p = cow.positions
+        w = np.stack([((m[r, 0] * p[:, 0] + m[r, 1] * p[:, 1]) + m[r, 2] * p[:, 2]) + m[r, 3] for r in range(3)], axis=1)
+        pos.append(w)
+        tris.append(cow.triangles + np.uint32(k * len(p)))
+    soup = MeshData(np.concatenate(pos), np.concatenate(tris).astype(np.uint32), None, "soup")
+    mat = Material(diffuse=(0.7, 0.6, 0.5), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    return Scene(root=Node.group([Node.geo(Mesh(soup), mat)]), lights=scene.lights, ambient=scene.ambient), cam, size
+
+
+SYNTHETIC = {"big-mesh": big_mesh, "big-soup": big_soup}
