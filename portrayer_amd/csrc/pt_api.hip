@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/portrayer_hip.h"
@@ -41,7 +42,8 @@ template <int MODE, bool STATS>
 __device__ __forceinline__ void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const PtStack& stk, PtCounters* cnt) {
     if (MODE == PT_MODE_KD) pt_trace_kd<STATS>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
-    else pt_trace_flat<STATS, true>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);
+    else pt_trace_flat<STATS, true, false>(sc, ray, any, hit, stk, cnt);
 }
 
 __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCounters& c) {
@@ -372,6 +374,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     std::vector<PtKdNode> mkd;
     std::vector<uint32_t> mkd_items;
     int max_kdm_depth = 0;
+    bool any_kdmesh = false;
     if (s->mesh_kd_root && s->n_kdm_nodes) {
         if (!s->kdm_axis || !s->kdm_plane || !s->kdm_front || !s->kdm_back || !s->kdm_first || !s->kdm_count || (s->n_kdm_items && !s->kdm_items) ||
             !s->mesh_kd_bounds || !s->mesh_kd_bounds_invtrans)
@@ -409,6 +412,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
             }
             PtMeshInfo& mi = meshes[m];
             mi.kd_root = root;
+            any_kdmesh = true;
             const double* b = s->mesh_kd_bounds + 6 * (size_t)m;
             double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
             mi.kd_extent = (dx * dx + dy * dy) + dz * dz;  // bounding_box.rs:95-99
@@ -593,7 +597,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
     v.kd_extent = kd_extent;
     v.mkd = (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;
-    v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : PT_MODE_FLAT);
+    v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
     int below = std::max(max_blas_depth, 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
     int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + below + 2 : tlas.depth + below + 4;
     v.stack_cap = std::max(cap, 8);
@@ -661,6 +665,7 @@ static hipError_t pt_dispatch_mode(const PtRenderArgs& a, bool stats, int n_cu, 
 static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
     if (a.scene.mode == PT_MODE_FLAT_NOMESH) return pt_dispatch_mode<PT_MODE_FLAT_NOMESH>(a, stats, n_cu, stream, grid, launch);
     if (a.scene.mode == PT_MODE_KD) return pt_dispatch_mode<PT_MODE_KD>(a, stats, n_cu, stream, grid, launch);
+    if (a.scene.mode == PT_MODE_FLAT_KDMESH) return pt_dispatch_mode<PT_MODE_FLAT_KDMESH>(a, stats, n_cu, stream, grid, launch);
     return pt_dispatch_mode<PT_MODE_FLAT>(a, stats, n_cu, stream, grid, launch);
 }
 
@@ -916,14 +921,21 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     PT_HIP(c, hipMemcpy(d_d, directions, n * 24, hipMemcpyHostToDevice));
     size_t lds = (size_t)c->view.stack_cap * PT_BLOCK * 4;
     dim3 grid((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK));
-    if (lds > 64 * 1024) {
-        const void* f = c->view.mode == PT_MODE_FLAT_NOMESH ? reinterpret_cast<const void*>(&pt_cast_kernel<PT_MODE_FLAT_NOMESH>)
-                        : (c->view.mode == PT_MODE_KD ? reinterpret_cast<const void*>(&pt_cast_kernel<PT_MODE_KD>) : reinterpret_cast<const void*>(&pt_cast_kernel<PT_MODE_FLAT>));
-        PT_HIP(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto cast = [&](auto mode) -> hipError_t {
+        constexpr int M = decltype(mode)::value;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_cast_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(pt_cast_kernel<M>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
+        return hipSuccess;
+    };
+    switch (c->view.mode) {
+    case PT_MODE_FLAT_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT_NOMESH>())); break;
+    case PT_MODE_KD: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_KD>())); break;
+    case PT_MODE_FLAT_KDMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT_KDMESH>())); break;
+    default: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT>())); break;
     }
-    if (c->view.mode == PT_MODE_FLAT_NOMESH) hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_FLAT_NOMESH>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
-    else if (c->view.mode == PT_MODE_KD) hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_KD>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
-    else hipLaunchKernelGGL(pt_cast_kernel<PT_MODE_FLAT>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
     PT_HIP(c, hipGetLastError());
     PT_HIP(c, hipDeviceSynchronize());
     PT_HIP(c, hipMemcpy(out_t, d_t, n * 8, hipMemcpyDeviceToHost));

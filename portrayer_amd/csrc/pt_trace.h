@@ -187,7 +187,7 @@ PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay
 
 // flat_scene.rs:71-99 for one flattened node: transform the ray into model space, dispatch on the
 // primitive (primitive.rs:55-62), keep the hit if it beats `best`. Returns true if best changed.
-template <bool STATS>
+template <bool STATS, bool MESH = true>
 PT_HD bool pt_test_node(const PtSceneView& sc, uint32_t node, const PtRay& ray, double start, PtHit& best, bool any,
                         const PtStack& stk, int sp, PtCounters* cnt) {
     const uint32_t* info = sc.info + 4 * (size_t)node;
@@ -209,6 +209,7 @@ PT_HD bool pt_test_node(const PtSceneView& sc, uint32_t node, const PtRay& ray, 
         break;
     }
     default: {  // PT_MESH / PT_KDMESH: mesh.rs:146-167 (box test, then the nearest triangle)
+        if (!MESH) return false;  // PT_MODE_FLAT_NOMESH: the host guarantees there is none
         const PtMeshInfo& m = sc.meshes[data];
         if (type == PT_KDMESH && m.kd_root >= 0) {
             uint32_t tri = 0;
@@ -253,7 +254,7 @@ PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool an
         [&](uint32_t first, uint32_t count, int sp) -> bool {
             for (uint32_t i = 0; i < count; i++) {
                 uint32_t node = sc.bvh_items[first + i];
-                if (pt_test_node<STATS>(sc, node, ray, PT_EPSILON, best, any, stk, sp, cnt) && any) return true;
+                if (pt_test_node<STATS, false>(sc, node, ray, PT_EPSILON, best, any, stk, sp, cnt) && any) return true;
             }
             return false;
         }, cnt);
@@ -272,7 +273,7 @@ PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool an
 #define PT_REF_MARKER 0xFFFFFFFEu
 // MESH = false compiles the mesh-instance path out (scenes of analytic primitives and stand-alone
 // triangles only): fewer live registers in the hot loop.
-template <bool STATS, bool MESH>
+template <bool STATS, bool MESH, bool KDMESH = MESH>
 PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
     best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
     if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return false;
@@ -323,7 +324,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                 uint32_t type = info[0], data = info[1];
                 PtRay lr = pt_ray_to_local(sc.inv + 12 * (size_t)item, ray);  // flat_scene.rs:74
                 if (STATS) cnt->n_analytic++;
-                if (MESH && type == PT_KDMESH && sc.meshes[data].kd_root >= 0) {  // the reference's own triangle tree (quirk Q3)
+                if (MESH && KDMESH && type == PT_KDMESH && sc.meshes[data].kd_root >= 0) {  // the reference's own triangle tree (quirk Q3)
                     double t; uint32_t tri = 0;
                     if (pt_kdmesh_hit<STATS>(sc, sc.meshes[data], lr, PT_EPSILON, pt_cand_end(best, item, 0), stk, sp, &t, &tri, cnt)) {
                         best.t = t; best.node = item; best.sub = tri;
