@@ -113,6 +113,7 @@ def main():
     example, n, w, h, s = WORKLOADS[args.workload]
     w, h, s = args.width or w, args.height or h, args.samples or s
     device = 0 if args.same_device else local_rank
+    t_prep0 = time.perf_counter()
     if example.startswith("synthetic:"):
         import example_scenes
         import host_glue
@@ -122,7 +123,9 @@ def main():
     else:
         scene = host.Scene.example(example, n=n or 10)
     traverse = H.TRAVERSE_KD if args.traversal == "kd" else H.TRAVERSE_FLAT
+    t_prep1 = time.perf_counter()
     renderer = host.Renderer(scene, traverse, kd_depth=10, device=device)  # flatten + build + upload: once, outside the timed region
+    t_prep2 = time.perf_counter()
     ctx = renderer.context
     lib = H.lib()
     cam = host.camera(scene.camera, w, h)
@@ -204,6 +207,8 @@ def main():
         for k, x in zip(keys, t.tolist()):
             total[k] = int(x)
     rays_frame = total["primary"] + total["shadow"] + total["reflect"] + total["refract"]
+    if os.environ.get("PT_DUMP_COUNTERS") and rank == 0:  # kernel experiments (profiles/ab.sh builds with -DPT_PHASE_TIMING)
+        print("counters", json.dumps({k: int(v) if isinstance(v, (int, np.integer)) else v for k, v in counts.items()}), file=sys.stderr)
 
     for _ in range(args.warmup):
         step()
@@ -244,6 +249,7 @@ def main():
                        "width": w, "height": h, "samples": s, "traversal": args.traversal, "sampling": "counter-based jitter, seed 0",
                        "partition": f"8x8 tiles round-robin over {world} rank(s), one gather" if world > 1 else "single GPU",
                        "rays_per_frame": rays_frame,
+                       "prepare_ms": {"scene_script": (t_prep1 - t_prep0) * 1e3, "flatten_build_upload": (t_prep2 - t_prep1) * 1e3},
                        "rays": {k: total[k] for k in ("primary", "shadow", "reflect", "refract")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": measured_traffic(args.workload, args.traversal, world) if (w, h, s) == WORKLOADS[args.workload][2:] and args.share == 1 else None,

@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
     PtHit hit;
     hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
     bool exhausted = false;
+#ifdef PT_PHASE_TIMING
+    unsigned long long c_prev = __builtin_readcyclecounter();
+#endif
     unsigned q_next = 0, q_end = 0, q_seen = 0;  // this wavefront's private batch of work items; highest item index seen handed out
 
     for (;;) {
@@ -119,8 +122,25 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
         }
         bool active = L.work != PT_IDLE;
         if (!__any(active || !exhausted)) break;
+#ifdef PT_PHASE_TIMING  // experiment (profiles/phase.sh): wave cycles spent shading / tracing / handing out work, reported in n_tri / n_bbox / kd_plane_miss
+        unsigned long long c0 = __builtin_readcyclecounter();
+#endif
+        if (a.sample_barrier) {
+            // Lanes that are about to start a sample wait until no lane of the wavefront is in the middle of
+            // one: the rays a wavefront traces together are then of one kind (64 neighbouring primary rays,
+            // then their shadow rays to light 0, ...) and walk the trees together.
+            bool mid = active && !(L.stage == PT_ST_NEW_SAMPLE && !L.has_ray);
+            if (__any(mid)) active = mid;
+        }
         if (active) pt_lane_advance<STATS, TEX>(a, L, hit, fr, &cnt);
+#ifdef PT_PHASE_TIMING
+        unsigned long long c1 = __builtin_readcyclecounter();
+#endif
         if (L.work != PT_IDLE && L.has_ray) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
+#ifdef PT_PHASE_TIMING
+        unsigned long long c2 = __builtin_readcyclecounter();
+        if (STATS) { cnt.n_tri += c1 - c0; cnt.n_bbox += c2 - c1; cnt.kd_plane_miss += c0 - c_prev; c_prev = c2; }
+#endif
     }
     if (STATS) pt_flush_counters(a.counters, cnt);
 }
@@ -332,6 +352,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     std::vector<uint32_t> items;
     std::vector<PtBuildBox> mesh_box(s->n_meshes);
     int max_blas_depth = 0;
+    int blas_leaf = 2;  // triangles per mesh-tree leaf (measured: 2 beats 1, 3 and 4 by 2-5 % on cows / big-soup)
+    if (const char* e = getenv("PORTRAYER_BLAS_LEAF")) blas_leaf = std::max(1, atoi(e));
     for (uint32_t m = 0; m < s->n_meshes; m++) {
         uint64_t v0 = s->mesh_vert_off[m], v1 = s->mesh_vert_off[m + 1], t0 = s->mesh_tri_off[m], t1 = s->mesh_tri_off[m + 1];
         if (v1 <= v0) return pt_fail(c, PT_ERR_SCENE, "meshes must have at least one vertex (mesh.rs:71)");
@@ -359,7 +381,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
             boxes[t - t0] = b;
             ids[t - t0] = (uint32_t)t;
         }
-        PtBvhRef ref = pt_bvh_build(boxes.data(), ids.data(), boxes.size(), 4, bvh, items);
+        PtBvhRef ref = pt_bvh_build(boxes.data(), ids.data(), boxes.size(), blas_leaf, bvh, items);
         max_blas_depth = std::max(max_blas_depth, ref.depth);
         PtMeshInfo& mi = meshes[m];
         for (int r = 0; r < 12; r++) mi.bbox_inv[r] = s->mesh_bounds_invtrans ? s->mesh_bounds_invtrans[16 * (size_t)m + r] : 0.0;
@@ -691,6 +713,8 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     uint32_t grid = 0;
     PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
+    a.sample_barrier = 1;  // measured +25 % (big-scene, big-soup) to +41 % (mirror): profiles/r01/notes.md step k
+    if (const char* e = getenv("PORTRAYER_SAMPLE_BARRIER")) a.sample_barrier = atoi(e) != 0;
     a.work_div = std::max<uint32_t>(grid * (PT_BLOCK / 64) * 8u, 1u);  // batch = remaining work / (8 x resident wavefronts)
     int rc = pt_reserve(c, c->frames, (size_t)a.n_lanes * PT_FRAME_DEPTHS * PT_FRAME_SLOTS * sizeof(double));
     if (rc) return rc;

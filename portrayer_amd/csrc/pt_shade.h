@@ -67,6 +67,7 @@ struct PtRenderArgs {
     uint32_t n_lanes;
     unsigned int* work_counter;
     uint32_t work_div;               // a wavefront takes (remaining work / work_div) items from work_counter at a time
+    uint32_t sample_barrier;         // 1: lanes wait at the start of a sample until every lane of the wavefront is there
     PtCounters* counters;
 };
 
@@ -316,6 +317,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 fr.store3(PT_SUM_DEPTH, 0, value);
                 L.sample++;
                 L.stage = PT_ST_NEW_SAMPLE;
+                if (a.sample_barrier) return;  // the wavefront starts its next samples together (pt_render_kernel)
                 continue;
             }
             L.depth--;
