@@ -100,7 +100,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     import ctypes as C
@@ -275,6 +274,9 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         sys.stderr.flush()
+        # RCCL writes its version banner through C stdio, which is flushed at exit - after this line -
+        # when stdout is a pipe or a file: flush it now so that the JSON is the last line on stdout
+        C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)  # the one JSON line, last thing on rank 0's stdout
 
 

@@ -40,13 +40,22 @@ inline double half_area(const PtBuildBox& b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-// f64 -> f32 rounded toward -inf / +inf (boxes may only grow)
+// f64 -> f32 rounded toward -inf / +inf (boxes may only grow), kept inside [-1e18, 1e18] and finite:
+// the device slab test (pt_slab32) multiplies plane coordinates by reciprocals up to 1e18 and must
+// not overflow. A coordinate beyond the limit or a NaN (degenerate transform) opens the box to the
+// limit on that side, so such a node is simply always visited; rays are assumed to start within
+// the same +-1e18.
+#define PT_BOX_LIMIT 1e18
 inline float round_down(double v) {
+    if (!(v > -PT_BOX_LIMIT)) return -(float)PT_BOX_LIMIT;  // also NaN
+    if (v > PT_BOX_LIMIT) return (float)PT_BOX_LIMIT;
     float f = (float)v;
     if ((double)f > v) f = std::nextafterf(f, -INFINITY);
     return f;
 }
 inline float round_up(double v) {
+    if (!(v < PT_BOX_LIMIT)) return (float)PT_BOX_LIMIT;  // also NaN
+    if (v < -PT_BOX_LIMIT) return -(float)PT_BOX_LIMIT;
     float f = (float)v;
     if ((double)f < v) f = std::nextafterf(f, INFINITY);
     return f;

@@ -44,36 +44,55 @@ PT_HD double pt_pop_f64(const PtStack& s, int& sp) {
     return c.d;
 }
 
-// Single-precision ray for the tree walk, with the bounds that keep the f32 slab test conservative:
-// o_hi >= o >= o_lo component-wise (the f64 origin lies between them), inv = fl32(1 / d).
+// Single-precision ray for the tree walk. The slab test evaluates (plane - o) / d as
+// fma(plane, inv, -o * inv) with the per-ray constants rounded so that every error makes the overlap
+// LONGER: inv = fl32(1 / d); the lower planes use n0 = -(o_hi * inv), the upper planes n1 = -(o_lo * inv)
+// (o_hi >= o >= o_lo bound the f64 origin in f32), each then pushed by 2^-22 relative in the direction
+// that moves a near plane nearer and a far plane farther (which plane is near depends on the sign of
+// inv). An axis the ray is parallel to (|inv| > 1e18, which also keeps every product below FLT_MAX
+// for the |coordinates| <= 1e18 that pt_scene_upload guarantees for boxes) is switched off:
+// inv = 0, n0 = -inf, n1 = +inf give the interval (-inf, +inf).
 struct PtRay32 {
-    float ohx, ohy, ohz, olx, oly, olz, ix, iy, iz;
+    float ix, iy, iz, n0x, n0y, n0z, n1x, n1y, n1z;
 };
+PT_HD void pt_ray32_axis(double o, double d, float* inv, float* n0, float* n1) {
+    float x = (float)o;
+    const float e = 2.4e-7f;  // > 2^-23: covers the rounding of the conversion and of the bound itself
+    float ex = fabsf(x) * e + 1e-37f;
+    float oh = x + ex, ol = x - ex;
+    float i = (float)(1.0 / d);
+    if (!(fabsf(i) <= 1e18f)) {  // parallel (or NaN): no constraint from this axis
+        *inv = 0.0f; *n0 = -INFINITY; *n1 = INFINITY;
+        return;
+    }
+    float c0 = oh * i, c1 = ol * i;
+    float w0 = fabsf(c0) * 4.8e-7f + 1e-37f, w1 = fabsf(c1) * 4.8e-7f + 1e-37f;
+    // i > 0: the lower plane is the near one (make it nearer: larger c0), the upper plane the far one (smaller c1); i < 0: the other way round
+    c0 = i > 0.0f ? c0 + w0 : c0 - w0;
+    c1 = i > 0.0f ? c1 - w1 : c1 + w1;
+    *inv = i; *n0 = -c0; *n1 = -c1;
+}
 PT_HD PtRay32 pt_ray32(const PtRay& r) {
     PtRay32 q;
-    float x = (float)r.o.x, y = (float)r.o.y, z = (float)r.o.z;
-    const float e = 2.4e-7f;  // > 2^-23: covers the rounding of the conversion and of the bound itself
-    float ex = fabsf(x) * e + 1e-37f, ey = fabsf(y) * e + 1e-37f, ez = fabsf(z) * e + 1e-37f;
-    q.ohx = x + ex; q.ohy = y + ey; q.ohz = z + ez;
-    q.olx = x - ex; q.oly = y - ey; q.olz = z - ez;
-    q.ix = (float)(1.0 / r.d.x); q.iy = (float)(1.0 / r.d.y); q.iz = (float)(1.0 / r.d.z);
+    pt_ray32_axis(r.o.x, r.d.x, &q.ix, &q.n0x, &q.n1x);
+    pt_ray32_axis(r.o.y, r.d.y, &q.iy, &q.n0y, &q.n1y);
+    pt_ray32_axis(r.o.z, r.d.z, &q.iz, &q.n0z, &q.n1z);
     return q;
 }
 
-// Slab test of one child box against [0, tmax] in f32. Conservative by construction: the lower
-// planes are measured from o_hi and the upper planes from o_lo (so every numerator errs towards a
-// longer overlap for either sign of the direction), the final interval is widened by 2^-20 relative
-// (sub + mul + reciprocal roundings are < 2^-22), NaNs (0 * inf) fall out of fminf / fmaxf, and the
-// comparison is written so that an unordered result accepts the box.
+// Slab test of one child box against [0, tmax] in f32. Conservative by construction (see PtRay32);
+// the final interval is widened by 2^-20 relative (fma + reciprocal roundings are < 2^-22), NaNs
+// cannot arise from finite boxes, and the comparison is written so that an unordered result accepts
+// the box anyway.
 PT_HD bool pt_slab32(const float* lo, const float* hi, const PtRay32& q, float tmax, float* tnear) {
-    float x0 = (lo[0] - q.ohx) * q.ix, x1 = (hi[0] - q.olx) * q.ix;
-    float y0 = (lo[1] - q.ohy) * q.iy, y1 = (hi[1] - q.oly) * q.iy;
-    float z0 = (lo[2] - q.ohz) * q.iz, z1 = (hi[2] - q.olz) * q.iz;
+    float x0 = __builtin_fmaf(lo[0], q.ix, q.n0x), x1 = __builtin_fmaf(hi[0], q.ix, q.n1x);
+    float y0 = __builtin_fmaf(lo[1], q.iy, q.n0y), y1 = __builtin_fmaf(hi[1], q.iy, q.n1y);
+    float z0 = __builtin_fmaf(lo[2], q.iz, q.n0z), z1 = __builtin_fmaf(hi[2], q.iz, q.n1z);
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     const float w = 9.6e-7f;
-    tn = fmaxf(tn - fabsf(tn) * w, 0.0f);
-    tf = fminf(tf + fabsf(tf) * w, tmax);
+    tn = fmaxf(__builtin_fmaf(fabsf(tn), -w, tn), 0.0f);
+    tf = fminf(__builtin_fmaf(fabsf(tf), w, tf), tmax);
     *tnear = tn;
     return !(tn > tf);
 }
