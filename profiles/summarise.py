@@ -19,7 +19,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
         for k, v in agg.items():
             out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
 for line in open(f"{dst}/{tag}_kernel_stats.csv"):
-    if "pt_render_kernel" in line and "false" in line:
+    if "pt_render_kernel<" in line and ", false, " in line:  # the timed kernel (STATS = false), not the counting launch
         out["kernel_trace_avg_ns"] = float(line.split('","')[-5] if False else line.strip().split(",")[-5].strip('"'))
 json.dump(out, open(f"{dst}/{tag}_pmc.json", "w"), indent=1)
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
