@@ -81,7 +81,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare rank 0's assembled image with a single-GPU render")
     ap.add_argument("--force-dist", action="store_true", help="testing: take the torch.distributed path even with one rank")
-    ap.add_argument("--share", type=int, default=1, help="testing: render only rank 0's tiles of an N-rank partition (no gather)")
+    ap.add_argument("--share", type=int, default=1, help="testing: render only one rank's tiles of an N-rank partition (no gather)")
+    ap.add_argument("--share-rank", type=int, default=0, help="testing: which rank's tiles --share renders")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,7 +142,7 @@ def main():
     check(lib.pt_copy_to_device(ctx, d_bg, bg.ctypes.data_as(C.c_void_p), bg.nbytes), "pt_copy_to_device")
 
     def params(stats):
-        return H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, rank, world if args.share == 1 else args.share, 1 if stats else 0)
+        return H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, rank if args.share == 1 else args.share_rank, world if args.share == 1 else args.share, 1 if stats else 0)
 
     p = params(False)
     compact_bytes = int(lib.pt_compact_bytes(C.byref(p)))

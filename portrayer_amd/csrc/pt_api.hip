@@ -31,8 +31,11 @@
 #ifndef PT_WORK_BATCH_MAX
 #define PT_WORK_BATCH_MAX 256  // most work items a wavefront takes from the global counter at a time
 #endif
+// Waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument) is a
+// template parameter of the render kernel: 3 (168 VGPRs) where shading weighs in, 4 (128 VGPRs, more
+// spills, more latency hiding) where the tree walk dominates - chosen per scene in pt_scene_upload.
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument); measured best, profiles/r01/notes.md
+#define PT_MIN_WAVES 0  // experiments: force one value for every scene (profiles/ab.sh)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -53,8 +56,8 @@ __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCount
         if (s[i]) atomicAdd(d + i, s[i]);
 }
 
-template <int MODE, bool STATS, bool TEX>
-__global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRenderArgs a) {
+template <int MODE, bool STATS, bool TEX, int WAVES>
+__global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES) pt_render_kernel(PtRenderArgs a) {
     extern __shared__ uint32_t pt_lds[];
     PtStack stk;
     stk.base = pt_lds + threadIdx.x;
@@ -223,6 +226,7 @@ struct pt_context {
     PtBuf frames, accum, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
     PtSceneView view;
     bool have_scene = false;
+    int waves = 3;  // occupancy variant of the render kernel for this scene (pt_dispatch)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool pending = false;
     bool pending_stats = false;
@@ -620,6 +624,18 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.kd_extent = kd_extent;
     v.mkd = (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;
     v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
+    // mesh-heavy scenes spend > 90 % of the wave cycles in the tree walk and gain from a 4th wave (big-soup 2.46 -> 2.75 Gray/s);
+    // scenes with a few small meshes lose (mirror 11.8 -> 10.7, cows 8.9 -> 7.8)
+    // and so does the reference's k-d tree on small scenes (mirror KD 3.8 -> 3.6) but not on big-scene (1.40 -> 1.65).
+    {
+        double instanced = 0.0;  // primitives a ray can meet, mesh instances counted with their triangles
+        for (uint32_t i = 0; i < n; i++) {
+            int32_t t = s->prim_type[i];
+            instanced += (t == PT_PRIM_MESH || t == PT_PRIM_KDMESH) ? (double)(s->mesh_tri_off[s->prim_data[i] + 1] - s->mesh_tri_off[s->prim_data[i]]) : 1.0;
+        }
+        c->waves = traverse == PT_TRAVERSE_KD ? (n >= 256 ? 4 : 3) : (instanced >= 262144.0 ? 4 : 3);
+    }
+    if (const char* e = getenv("PORTRAYER_WAVES")) c->waves = atoi(e) == 4 ? 4 : 3;
     int below = std::max(max_blas_depth, 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
     int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + below + 2 : tlas.depth + below + 4;
     v.stack_cap = std::max(cap, 8);
@@ -658,11 +674,11 @@ static int pt_check_params(pt_context* c, const pt_camera* cam, const pt_render_
     return PT_OK;
 }
 
-template <int MODE, bool STATS, bool TEX>
+template <int MODE, bool STATS, bool TEX, int WAVES>
 static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
     size_t lds = (size_t)a.scene.stack_cap * PT_BLOCK * 4;
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX>, PT_BLOCK, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX, WAVES>, PT_BLOCK, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     uint32_t want = (a.n_work + PT_BLOCK - 1) / PT_BLOCK;
@@ -670,25 +686,29 @@ static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream,
     *grid_out = grid;
     if (!launch) return hipSuccess;
     if (lds > 64 * 1024) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int MODE>
+template <int MODE, int WAVES>
 static hipError_t pt_dispatch_mode(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
     const bool tex = a.scene.mat_maps != nullptr;
-    if (tex) return stats ? pt_launch<MODE, true, true>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true>(a, n_cu, stream, grid, launch);
-    return stats ? pt_launch<MODE, true, false>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false>(a, n_cu, stream, grid, launch);
+    if (tex) return stats ? pt_launch<MODE, true, true, WAVES>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true, WAVES>(a, n_cu, stream, grid, launch);
+    return stats ? pt_launch<MODE, true, false, WAVES>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false, WAVES>(a, n_cu, stream, grid, launch);
 }
 
-static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
-    if (a.scene.mode == PT_MODE_FLAT_NOMESH) return pt_dispatch_mode<PT_MODE_FLAT_NOMESH>(a, stats, n_cu, stream, grid, launch);
-    if (a.scene.mode == PT_MODE_KD) return pt_dispatch_mode<PT_MODE_KD>(a, stats, n_cu, stream, grid, launch);
-    if (a.scene.mode == PT_MODE_FLAT_KDMESH) return pt_dispatch_mode<PT_MODE_FLAT_KDMESH>(a, stats, n_cu, stream, grid, launch);
-    return pt_dispatch_mode<PT_MODE_FLAT>(a, stats, n_cu, stream, grid, launch);
+// `waves` = pt_context::waves (3 or 4). Scenes of analytic primitives always take 3 and the
+// others as pt_scene_upload decided (measured: big-scene 14.2 vs 13.0 Gray/s at 3 vs 4).
+static hipError_t pt_dispatch(const PtRenderArgs& a, int waves, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
+    if (a.scene.mode == PT_MODE_FLAT_NOMESH) return pt_dispatch_mode<PT_MODE_FLAT_NOMESH, 3>(a, stats, n_cu, stream, grid, launch);
+    if (a.scene.mode == PT_MODE_KD)
+        return waves == 4 ? pt_dispatch_mode<PT_MODE_KD, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_KD, 3>(a, stats, n_cu, stream, grid, launch);
+    if (a.scene.mode == PT_MODE_FLAT_KDMESH)
+        return waves == 4 ? pt_dispatch_mode<PT_MODE_FLAT_KDMESH, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_FLAT_KDMESH, 3>(a, stats, n_cu, stream, grid, launch);
+    return waves == 4 ? pt_dispatch_mode<PT_MODE_FLAT, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_FLAT, 3>(a, stats, n_cu, stream, grid, launch);
 }
 
 static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_params* p, PtRenderArgs* a) {
@@ -711,7 +731,7 @@ static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_par
 
 static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStream_t stream) {
     uint32_t grid = 0;
-    PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
+    PT_HIP(c, pt_dispatch(a, c->waves, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
     a.sample_barrier = 1;  // measured +25 % (big-scene, big-soup) to +41 % (mirror): profiles/r01/notes.md step k
     if (const char* e = getenv("PORTRAYER_SAMPLE_BARRIER")) a.sample_barrier = atoi(e) != 0;
@@ -727,7 +747,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters), stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
     if (a.n_work) {
-        PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, true));
+        PT_HIP(c, pt_dispatch(a, c->waves, stats, c->n_cu, stream, &grid, true));
         hipLaunchKernelGGL(pt_finish_kernel, dim3((a.n_slots + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, stream, a);
         PT_HIP(c, hipGetLastError());
     }

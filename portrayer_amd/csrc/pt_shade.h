@@ -32,7 +32,9 @@
 // sample index), then the chunk sums sequentially (ascending chunk index). This is the build's
 // summation contract (the reference's rayon reduce has no fixed association, render.rs:36-43); it
 // lets several lanes share one pixel, which keeps all lanes busy when a GPU owns few pixels.
+#ifndef PT_SAMPLE_CHUNK
 #define PT_SAMPLE_CHUNK 8
+#endif
 // A compiler-only fence: stops hipcc from hoisting the loads of one interpreter state above the
 // stores of the previous one (register pressure), costs no instruction.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_STATE_FENCE)
