@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+VALU_PEAK_TFLOPS = 39.3  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz scalar-per-lane VALU ops/s (the guide's 157.3 TF FP32 vector peak = this x 2 for fma x 2 for packed f32)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 WORKLOADS = {
@@ -52,6 +53,16 @@ def algorithmic_bytes(st, n_lights, pixels, traversal):
     node_bytes = 16 if traversal == "kd" else 56
     return (56 * rays + node_bytes * st["n_inner"] + 104 * st["n_analytic"] + 72 * st["n_tri"] + 48 * st["n_bbox"]
             + st["hits"] * (168 + 80 + 120 * n_lights) + 27 * pixels)
+
+
+def algorithmic_flops(st, n_lights, traversal):
+    """SURVEY §8(d) "algorithmic flops per test" (f64 mul / add / div / sqrt / pow each = 1; an fma of
+    the f32 box test = 2): ray->model transform 30 + an average analytic primitive 60 per primitive
+    test; triangle 50; mesh box test 30 + 96; tree step 48 (two boxes x (6 fma + 12 min/max)) in this
+    build's tree or 9 per k-d split; per shaded hit 60 (point, normal, normalise) + 43 per light."""
+    node = 9 if traversal == "kd" else 48
+    return (node * st["n_inner"] + 90 * st["n_analytic"] + 50 * st["n_tri"] + 126 * st["n_bbox"]
+            + st["hits"] * (60 + 43 * n_lights))
 
 
 def measured_traffic(workload, traversal, n_gpus):
@@ -255,6 +266,10 @@ def main():
                          "traffic": measured_traffic(args.workload, args.traversal, world) if (w, h, s) == WORKLOADS[args.workload][2:] and args.share == 1 else None,
                          "kernel": "pt_render_kernel", "kernel_ms": mean_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": mine_bytes,
+                         # secondary ceiling: the scenes are cache-resident, the kernel is bound by VALU issue.
+                         # MI355X vector f64 = 78.6 TFLOP/s counting an fma as 2; parity forbids contraction, so 39.3 T mul-or-add/s
+                         "valu": {"achieved": algorithmic_flops(counts, n_lights, args.traversal) / mean_kernel_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": algorithmic_flops(counts, n_lights, args.traversal) / mean_kernel_s / 1e12 / VALU_PEAK_TFLOPS},
                          "per_ray": {"inner_nodes": total["n_inner"] / rays_frame, "primitive_tests": total["n_analytic"] / rays_frame,
                                      "triangle_tests": total["n_tri"] / rays_frame}},
         }
