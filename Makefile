@@ -23,14 +23,18 @@ examples/bin/%: examples/%.cpp portrayer_amd/libportrayer_host.so
 	@mkdir -p examples/bin
 	$(CXX) $(CXXFLAGS) -fPIE -DPORTRAYER_EXAMPLE_MAIN $< -o $@ -Lportrayer_amd -lportrayer_host -lportrayer_hip -Wl,-rpath,'$$ORIGIN/../../portrayer_amd'
 
-portrayer_amd/libportrayer_hip.so: $(CSRC)/pt_api.hip $(HIP_HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/pt_api.hip -o $@
+# two translation units (render path / device-side tree build), compiled side by side under make -j
+$(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+portrayer_amd/libportrayer_hip.so: $(CSRC)/pt_api.o $(CSRC)/pt_build.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared $^ -o $@
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f portrayer_amd/*.so
+	rm -f portrayer_amd/*.so $(CSRC)/*.o
 	rm -rf examples/bin
 	$(MAKE) -C oracle clean
 .PHONY: all oracle clean

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/portrayer_hip.h"
+#include "pt_build.h"
 #include "pt_bvh.h"
 #include "pt_shade.h"
 
@@ -328,6 +329,14 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     PT_HIP(c, hipSetDevice(c->device));
     c->have_scene = false;
     const uint32_t n = s->n_nodes;
+    const bool verbose = getenv("PORTRAYER_VERBOSE") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!verbose) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pt_scene_upload] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_begin).count());
+        t_begin = now;
+    };
 
     // ---- triangles: every mesh expanded to 72-byte vertex records, stand-alone triangles appended
     std::vector<uint64_t> tri_first(s->n_meshes + 1, 0);
@@ -357,7 +366,16 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     std::vector<PtBuildBox> mesh_box(s->n_meshes);
     int max_blas_depth = 0;
     int blas_leaf = 2;  // triangles per mesh-tree leaf (measured: 2 beats 1, 3 and 4 by 2-5 % on cows / big-soup)
-    if (const char* e = getenv("PORTRAYER_BLAS_LEAF")) blas_leaf = std::max(1, atoi(e));
+    if (const char* e = getenv("PORTRAYER_BLAS_LEAF")) blas_leaf = std::min(std::max(1, atoi(e)), 8);
+    // Where a mesh's triangle tree is built: on the host (binned SAH, pt_bvh.h: the better tree) or on the
+    // device (Morton-order tree, pt_build.h: ~100x faster to build). PORTRAYER_BUILD = host | device | auto;
+    // auto takes the device for meshes of PORTRAYER_BUILD_MIN (default 65536) triangles or more.
+    int build_mode = 2;
+    size_t device_build_min = 65536;
+    if (const char* e = getenv("PORTRAYER_BUILD")) build_mode = !strcmp(e, "host") ? 0 : (!strcmp(e, "device") ? 1 : 2);
+    if (const char* e = getenv("PORTRAYER_BUILD_MIN")) device_build_min = (size_t)std::max(16, atoi(e));
+    struct DeviceMesh { uint32_t m, t0, count; double lo[3], hi[3], pad; };
+    std::vector<DeviceMesh> device_meshes;
     for (uint32_t m = 0; m < s->n_meshes; m++) {
         uint64_t v0 = s->mesh_vert_off[m], v1 = s->mesh_vert_off[m + 1], t0 = s->mesh_tri_off[m], t1 = s->mesh_tri_off[m + 1];
         if (v1 <= v0) return pt_fail(c, PT_ERR_SCENE, "meshes must have at least one vertex (mesh.rs:71)");
@@ -367,8 +385,9 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         for (uint64_t v = 0; v < v1 - v0; v++)
             for (int k = 0; k < 3; k++) { mb.lo[k] = std::min(mb.lo[k], pos[3 * v + k]); mb.hi[k] = std::max(mb.hi[k], pos[3 * v + k]); }
         double ext = std::max(std::max(mb.hi[0] - mb.lo[0], mb.hi[1] - mb.lo[1]), std::max(mb.hi[2] - mb.lo[2], 1e-30));
-        std::vector<PtBuildBox> boxes(t1 - t0);
-        std::vector<uint32_t> ids(t1 - t0);
+        const bool on_device = (build_mode == 1 && t1 - t0 >= 16) || (build_mode == 2 && t1 - t0 >= device_build_min);
+        std::vector<PtBuildBox> boxes(on_device ? 0 : t1 - t0);
+        std::vector<uint32_t> ids(on_device ? 0 : t1 - t0);
         for (uint64_t t = t0; t < t1; t++) {
             PtBuildBox b = pt_bvh_detail::empty_box();
             for (int corner = 0; corner < 3; corner++) {
@@ -381,11 +400,22 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
                     b.lo[k] = std::min(b.lo[k], x); b.hi[k] = std::max(b.hi[k], x);
                 }
             }
+            if (on_device) continue;
             for (int k = 0; k < 3; k++) { b.lo[k] -= 1e-7 * ext; b.hi[k] += 1e-7 * ext; }
             boxes[t - t0] = b;
             ids[t - t0] = (uint32_t)t;
         }
-        PtBvhRef ref = pt_bvh_build(boxes.data(), ids.data(), boxes.size(), blas_leaf, bvh, items);
+        PtBvhRef ref;
+        ref.child = PT_REF_EMPTY; ref.depth = 0;
+        if (on_device) {  // built after the triangles are in HBM (below); the root is filled in then
+            DeviceMesh dm;
+            dm.m = m; dm.t0 = (uint32_t)t0; dm.count = (uint32_t)(t1 - t0);
+            for (int k = 0; k < 3; k++) { dm.lo[k] = mb.lo[k]; dm.hi[k] = mb.hi[k]; }
+            dm.pad = 1e-7 * ext;
+            device_meshes.push_back(dm);
+        } else {
+            ref = pt_bvh_build(boxes.data(), ids.data(), boxes.size(), blas_leaf, bvh, items);
+        }
         max_blas_depth = std::max(max_blas_depth, ref.depth);
         PtMeshInfo& mi = meshes[m];
         for (int r = 0; r < 12; r++) mi.bbox_inv[r] = s->mesh_bounds_invtrans ? s->mesh_bounds_invtrans[16 * (size_t)m + r] : 0.0;
@@ -396,6 +426,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         for (int k = 0; k < 3; k++) { mb.lo[k] -= 1e-5 * ext; mb.hi[k] += 1e-5 * ext; }
         mesh_box[m] = mb;
     }
+    lap("triangles + mesh trees");
     // ---- KDMesh triangle trees (reference structure)
     std::vector<PtKdNode> mkd;
     std::vector<uint32_t> mkd_items;
@@ -540,9 +571,34 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     }
 
     int rc;
+    lap("scene tree");
+    if ((rc = pt_upload(c, c->tri_v, tri_v))) return rc;
+    {   // tree arrays: the host-built part first, then room for the device-built mesh trees
+        size_t n_nodes = bvh.size(), n_items = items.size();
+        for (const DeviceMesh& dm : device_meshes) { n_nodes += PT_DEVICE_TREE_NODES(dm.count); n_items += dm.count; }
+        if (n_items >= (1u << 28) || n_nodes >= (1u << 31)) return pt_fail(c, PT_ERR_SCENE, "too many triangles for the 32-bit tree references");
+        if ((rc = pt_reserve(c, c->bvh, n_nodes * sizeof(PtBvhNode))) || (rc = pt_reserve(c, c->bvh_items, n_items * sizeof(uint32_t)))) return rc;
+        if (!bvh.empty()) PT_HIP(c, hipMemcpy(c->bvh.p, bvh.data(), bvh.size() * sizeof(PtBvhNode), hipMemcpyHostToDevice));
+        if (!items.empty()) PT_HIP(c, hipMemcpy(c->bvh_items.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        lap("upload triangles + host trees");
+        uint32_t node_base = (uint32_t)bvh.size(), item_base = (uint32_t)items.size();
+        float device_ms = 0.0f;
+        uint32_t treelets = 0;
+        for (const DeviceMesh& dm : device_meshes) {
+            PtDeviceBuildResult res;
+            PT_HIP(c, pt_device_build_mesh_tree((const double*)c->tri_v.p, dm.t0, dm.count, dm.lo, dm.hi, dm.pad, blas_leaf, (PtBvhNode*)c->bvh.p, node_base,
+                                                (uint32_t*)c->bvh_items.p, item_base, nullptr, &res));
+            meshes[dm.m].blas_root = res.root;
+            max_blas_depth = std::max(max_blas_depth, res.depth);
+            node_base += PT_DEVICE_TREE_NODES(dm.count); item_base += dm.count;
+            device_ms += res.ms; treelets += res.n_treelets;
+        }
+        if (verbose && !device_meshes.empty()) fprintf(stderr, "[pt_scene_upload] device tree build: %zu mesh(es), %.2f ms of kernels, %u treelets under host-built top trees, depth %d\n", device_meshes.size(), device_ms, treelets, max_blas_depth);
+        lap("device mesh trees");
+    }
     if ((rc = pt_upload(c, c->inv, inv)) || (rc = pt_upload(c, c->fwd, fwd)) || (rc = pt_upload(c, c->nrm, nrm)) ||
-        (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_v, tri_v)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
-        (rc = pt_upload(c, c->meshes, meshes)) || (rc = pt_upload(c, c->bvh, bvh)) || (rc = pt_upload(c, c->bvh_items, items)) ||
+        (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
+        (rc = pt_upload(c, c->meshes, meshes)) ||
         (rc = pt_upload(c, c->kd, kdn)) || (rc = pt_upload(c, c->kd_items, kdi)) || (rc = pt_upload(c, c->mkd, mkd)) ||
         (rc = pt_upload(c, c->mkd_items, mkd_items)))
         return rc;
@@ -643,6 +699,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         v.mat_maps = (const int32_t*)c->mat_maps.p; v.uv_trans = (const double*)c->uv_trans.p; v.tex = (const PtTexInfo*)c->tex.p;
         v.tex_rgb = (const uint8_t*)c->tex_rgb.p; v.srgb_lut = (const double*)c->srgb_lut.p; v.tri_uv = (const double*)c->tri_uv.p;
     }
+    lap("upload the rest");
     if ((size_t)v.stack_cap * PT_BLOCK * 4 > 150 * 1024) return pt_fail(c, PT_ERR_SCENE, "traversal stack would not fit in LDS (tree too deep)");
     c->have_scene = true;
     return PT_OK;

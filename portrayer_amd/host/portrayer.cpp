@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -448,6 +449,7 @@ static void check(pt_context* ctx, int rc, const char* what) {
 }
 
 Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, int kd_depth, int device) : flat_(FlatScene::from(hier)) {
+    auto t_pack = std::chrono::steady_clock::now();
     const size_t n = flat_.root.size();
     std::vector<double> trans(16 * n), inv(16 * n), nrm(16 * n);
     std::vector<int32_t> type(n), data(n), flags(n), mat(n);
@@ -605,7 +607,11 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
         s.n_textures = (uint32_t)textures.size(); s.texture_size = tex_size.data(); s.texture_offset = tex_off.data(); s.texture_rgb = tex_rgb.data();
     }
 
+    const bool verbose = std::getenv("PORTRAYER_VERBOSE") != nullptr;
+    if (verbose) std::fprintf(stderr, "[Renderer] pack scene arrays %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pack).count());
+    auto t_ctx = std::chrono::steady_clock::now();
     int rc = pt_context_create(device, &ctx_);
+    if (verbose) std::fprintf(stderr, "[Renderer] pt_context_create %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ctx).count());
     if (rc != PT_OK) throw std::runtime_error("pt_context_create failed (" + std::to_string(rc) + "): no usable MI355X; this path has no CPU fallback");
     try {
         if (traversal == render::Traversal::KdTree) {

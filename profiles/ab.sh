@@ -3,8 +3,8 @@
 # run the bench. usage: bash profiles/ab.sh "<bench args>" "-DPT_MIN_WAVES=1" "-DPT_MIN_WAVES=2" ...
 BARGS=$1; shift
 for flags in "$@"; do
-  rm -f portrayer_amd/libportrayer_hip.so
-  make -s portrayer_amd/libportrayer_hip.so EXTRA_HIPFLAGS="$flags" > /dev/null 2>&1 || { echo "build failed: $flags"; continue; }
+  rm -f portrayer_amd/libportrayer_hip.so portrayer_amd/csrc/pt_api.o
+  make -s -j2 portrayer_amd/libportrayer_hip.so EXTRA_HIPFLAGS="$flags" > /dev/null 2>&1 || { echo "build failed: $flags"; continue; }
   for i in 1 2; do
     python bench.py --no-cpu-baseline $BARGS 2>&1 | tail -1 | python -c "
 import sys,json

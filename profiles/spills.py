@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tmp = "/tmp/pt_spills"
 shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp + "/include")
 for f in os.listdir(root + "/portrayer_amd/csrc"):
-    shutil.copy(root + "/portrayer_amd/csrc/" + f, tmp)
+    shutil.copy(root + "/portrayer_amd/csrc/" + f, tmp) if not f.endswith(".o") else None
 shutil.copy(root + "/include/portrayer_hip.h", tmp + "/include")
 src = open(tmp + "/pt_api.hip").read().replace("../../include/portrayer_hip.h", "include/portrayer_hip.h")
 open(tmp + "/pt_api.hip", "w").write(src)
