@@ -575,7 +575,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     if ((rc = pt_upload(c, c->tri_v, tri_v))) return rc;
     {   // tree arrays: the host-built part first, then room for the device-built mesh trees
         size_t n_nodes = bvh.size(), n_items = items.size();
-        for (const DeviceMesh& dm : device_meshes) { n_nodes += PT_DEVICE_TREE_NODES(dm.count); n_items += dm.count; }
+        for (const DeviceMesh& dm : device_meshes) { n_nodes += PT_DEVICE_TREE_NODES(dm.count); n_items += PT_DEVICE_TREE_ITEMS(dm.count, blas_leaf); }
         if (n_items >= (1u << 28) || n_nodes >= (1u << 31)) return pt_fail(c, PT_ERR_SCENE, "too many triangles for the 32-bit tree references");
         if ((rc = pt_reserve(c, c->bvh, n_nodes * sizeof(PtBvhNode))) || (rc = pt_reserve(c, c->bvh_items, n_items * sizeof(uint32_t)))) return rc;
         if (!bvh.empty()) PT_HIP(c, hipMemcpy(c->bvh.p, bvh.data(), bvh.size() * sizeof(PtBvhNode), hipMemcpyHostToDevice));
@@ -583,17 +583,17 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         lap("upload triangles + host trees");
         uint32_t node_base = (uint32_t)bvh.size(), item_base = (uint32_t)items.size();
         float device_ms = 0.0f;
-        uint32_t treelets = 0;
+        int rounds = 0;
         for (const DeviceMesh& dm : device_meshes) {
             PtDeviceBuildResult res;
             PT_HIP(c, pt_device_build_mesh_tree((const double*)c->tri_v.p, dm.t0, dm.count, dm.lo, dm.hi, dm.pad, blas_leaf, (PtBvhNode*)c->bvh.p, node_base,
                                                 (uint32_t*)c->bvh_items.p, item_base, nullptr, &res));
             meshes[dm.m].blas_root = res.root;
             max_blas_depth = std::max(max_blas_depth, res.depth);
-            node_base += PT_DEVICE_TREE_NODES(dm.count); item_base += dm.count;
-            device_ms += res.ms; treelets += res.n_treelets;
+            node_base += PT_DEVICE_TREE_NODES(dm.count); item_base += PT_DEVICE_TREE_ITEMS(dm.count, blas_leaf);
+            device_ms += res.ms; rounds += res.rounds;
         }
-        if (verbose && !device_meshes.empty()) fprintf(stderr, "[pt_scene_upload] device tree build: %zu mesh(es), %.2f ms of kernels, %u treelets under host-built top trees, depth %d\n", device_meshes.size(), device_ms, treelets, max_blas_depth);
+        if (verbose && !device_meshes.empty()) fprintf(stderr, "[pt_scene_upload] device tree build: %zu mesh(es), %.2f ms, %d clustering rounds, depth %d\n", device_meshes.size(), device_ms, rounds, max_blas_depth);
         lap("device mesh trees");
     }
     if ((rc = pt_upload(c, c->inv, inv)) || (rc = pt_upload(c, c->fwd, fwd)) || (rc = pt_upload(c, c->nrm, nrm)) ||

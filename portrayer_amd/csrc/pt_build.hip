@@ -1,44 +1,50 @@
 // Device-side build of mesh triangle trees: see pt_build.h.
 //
-//   1. pt_lbvh_prepare    per triangle: f64 bounds -> f32 box rounded outward, 63-bit Morton code of the box centre
-//   2. rocprim radix sort (key = Morton code, value = triangle)  -- the only library call; sorting is not this path's subject
-//   3. pt_lbvh_hierarchy  Karras 2012: every inner node finds its range of sorted leaves and its split in O(log n), all in parallel
-//   4. pt_lbvh_refit      bottom-up boxes: the second thread to reach a node merges its children's boxes and climbs on
-//   5. pt_lbvh_emit       nodes in the walk's format (two child boxes + two references per node); subtrees of <= max_leaf
-//                         triangles (contiguous in Morton order) become leaves
-//   6. pt_lbvh_treelets   the Morton tree's upper levels split space at the middle regardless of where the triangles are.
-//                         They are replaced: the subtrees of <= PT_TREELET triangles whose parents are larger ("treelets",
-//                         a few thousand) are handed to the host, which builds a binned-SAH tree over their boxes in a
-//                         millisecond or two (pt_bvh.h); its leaves point at the treelets' roots
-//   7. pt_lbvh_depth      longest path below a treelet root (the walk's LDS stack is sized from it + the top tree's depth)
+// Parallel locally-ordered clustering (Meister & Bittner, "Parallel Locally-Ordered Clustering for
+// Bounding Volume Hierarchy Construction", 2018), bottom-up:
+//
+//   1. pt_ploc_prepare  per triangle: f64 bounds -> f32 box rounded outward, 63-bit Morton code of the box centre
+//   2. rocprim radix sort (key = Morton code, value = triangle) -- library call; sorting is not this path's subject
+//   3. repeat until one cluster is left (the clusters stay in Morton order):
+//        pt_ploc_nearest  every cluster looks PT_PLOC_RADIUS places to either side for the neighbour whose union
+//                         with it has the smallest surface area
+//        pt_ploc_merge    clusters that chose each other merge: the lower one becomes the new node (written in the
+//                         walk's format: two child boxes + two references), the upper one retires; a node whose
+//                         children together hold <= max_leaf triangles becomes a leaf instead
+//        rocprim exclusive scan + pt_ploc_compact: close the gaps
+//   4. pt_ploc_depth    longest root-to-leaf path (the walk's LDS stack is sized from it)
+//
+// (A Morton-order tree a la Karras 2012 was measured first: 8.4 ms for 1.25 M triangles but 31 % slower to
+// walk than the host's binned-SAH tree, and replacing its upper levels by a host-built SAH tree over
+// "treelets" showed the loss sits in the LOWER levels: 2.42 Gray/s with 16-triangle treelets, 1.99 with
+// 256, 1.90 without, against 2.74 for the host tree.)
 #include "pt_build.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
-#include <vector>
-
-#include "pt_bvh.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #define PT_BUILD_BLOCK 256
-#define PT_LBVH_LEAF 0x80000000u
-#define PT_LBVH_NONE 0xFFFFFFFFu
-#ifndef PT_TREELET
-#define PT_TREELET 256u  // triangles per treelet (subtrees of the Morton tree kept as they are)
+#define PT_PLOC_LEAF 0x80000000u
+#define PT_PLOC_NONE 0xFFFFFFFFu
+#define PT_PLOC_LIMIT 1e18f  // pt_bvh.h PT_BOX_LIMIT: box coordinates stay finite and within +-1e18
+#ifndef PT_PLOC_RADIUS
+#define PT_PLOC_RADIUS 16
 #endif
-#define PT_LBVH_LIMIT 1e18f  // pt_bvh.h PT_BOX_LIMIT: box coordinates stay finite and within +-1e18
 
 namespace {
 
 __device__ __forceinline__ float pt_box_lo(double v) {
-    if (!(v > -1e18)) return -PT_LBVH_LIMIT;  // also NaN
-    if (v > 1e18) return PT_LBVH_LIMIT;
+    if (!(v > -1e18)) return -PT_PLOC_LIMIT;  // also NaN
+    if (v > 1e18) return PT_PLOC_LIMIT;
     return __double2float_rd(v);
 }
 __device__ __forceinline__ float pt_box_hi(double v) {
-    if (!(v < 1e18)) return PT_LBVH_LIMIT;
-    if (v < -1e18) return -PT_LBVH_LIMIT;
+    if (!(v < 1e18)) return PT_PLOC_LIMIT;
+    if (v < -1e18) return -PT_PLOC_LIMIT;
     return __double2float_ru(v);
 }
 
@@ -59,21 +65,27 @@ __device__ __forceinline__ unsigned long long pt_quantise21(double c, double lo,
     return (unsigned long long)u;
 }
 
-__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_lbvh_prepare(const double* __restrict__ tri_v, uint32_t tri_first, uint32_t n,
+struct PtBox6 {
+    float v[6];  // lo xyz, hi xyz
+};
+
+__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_ploc_prepare(const double* __restrict__ tri_v, uint32_t tri_first, uint32_t n,
                                                                  double lx, double ly, double lz, double ix, double iy, double iz, double pad,
                                                                  unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                                 float* __restrict__ leaf_box) {
+                                                                 PtBox6* __restrict__ tri_box) {
     uint32_t t = blockIdx.x * PT_BUILD_BLOCK + threadIdx.x;
     if (t >= n) return;
     const double* v = tri_v + 9 * (size_t)(tri_first + t);
     double lo[3], hi[3];
+    PtBox6 b;
     for (int k = 0; k < 3; k++) {
-        double a = v[k], b = v[3 + k], c = v[6 + k];
-        lo[k] = fmin(fmin(a, b), c);
-        hi[k] = fmax(fmax(a, b), c);
-        leaf_box[6 * (size_t)t + k] = pt_box_lo(lo[k] - pad);
-        leaf_box[6 * (size_t)t + 3 + k] = pt_box_hi(hi[k] + pad);
+        double a = v[k], bb = v[3 + k], c = v[6 + k];
+        lo[k] = fmin(fmin(a, bb), c);
+        hi[k] = fmax(fmax(a, bb), c);
+        b.v[k] = pt_box_lo(lo[k] - pad);
+        b.v[3 + k] = pt_box_hi(hi[k] + pad);
     }
+    tri_box[t] = b;
     unsigned long long qx = pt_quantise21(0.5 * (lo[0] + hi[0]), lx, ix);
     unsigned long long qy = pt_quantise21(0.5 * (lo[1] + hi[1]), ly, iy);
     unsigned long long qz = pt_quantise21(0.5 * (lo[2] + hi[2]), lz, iz);
@@ -81,156 +93,118 @@ __global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_lbvh_prepare(const double* 
     vals[t] = t;
 }
 
-// length of the common prefix of the keys of sorted leaves i and j; equal keys are told apart by their positions
-__device__ __forceinline__ int pt_delta(const unsigned long long* __restrict__ keys, int n, int i, int j) {
-    if (j < 0 || j >= n) return -1;
-    unsigned long long a = keys[i], b = keys[j];
-    if (a == b) return 64 + __clz((unsigned)(i ^ j));
-    return __clzll((long long)(a ^ b));
-}
-
-// Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees" (2012), section 3
-__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_lbvh_hierarchy(const unsigned long long* __restrict__ keys, int n, uint32_t* __restrict__ child,
-                                                                   uint32_t* __restrict__ range, uint32_t* __restrict__ node_parent,
-                                                                   uint32_t* __restrict__ leaf_parent) {
-    int i = (int)(blockIdx.x * PT_BUILD_BLOCK + threadIdx.x);
-    if (i >= n - 1) return;
-    int d = pt_delta(keys, n, i, i + 1) - pt_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
-    int dmin = pt_delta(keys, n, i, i - d);
-    int lmax = 2;
-    while (pt_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
-    int l = 0;
-    for (int t = lmax / 2; t >= 1; t /= 2)
-        if (pt_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-    int j = i + l * d;
-    int dnode = pt_delta(keys, n, i, j);
-    int s = 0, t = l;
-    do {
-        t = (t + 1) >> 1;
-        if (pt_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-    } while (t > 1);
-    int gamma = i + s * d + (d < 0 ? -1 : 0);
-    int first = i < j ? i : j, last = i < j ? j : i;
-    bool left_leaf = first == gamma, right_leaf = last == gamma + 1;
-    child[2 * i] = (uint32_t)gamma | (left_leaf ? PT_LBVH_LEAF : 0u);
-    child[2 * i + 1] = (uint32_t)(gamma + 1) | (right_leaf ? PT_LBVH_LEAF : 0u);
-    range[2 * i] = (uint32_t)first;
-    range[2 * i + 1] = (uint32_t)last;
-    if (left_leaf) leaf_parent[gamma] = (uint32_t)i; else node_parent[gamma] = (uint32_t)i;
-    if (right_leaf) leaf_parent[gamma + 1] = (uint32_t)i; else node_parent[gamma + 1] = (uint32_t)i;
-    if (i == 0) node_parent[0] = PT_LBVH_NONE;
-}
-
-// another CU may have written the sibling's box a moment ago: read it past this CU's L1
-__device__ __forceinline__ float pt_load_coherent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_lbvh_refit(int n, const uint32_t* __restrict__ vals, const float* __restrict__ leaf_box,
-                                                               const uint32_t* __restrict__ child, const uint32_t* __restrict__ node_parent,
-                                                               const uint32_t* __restrict__ leaf_parent, float* node_box, uint32_t* arrived,
-                                                               uint32_t tri_first, uint32_t* __restrict__ items) {
-    int k = (int)(blockIdx.x * PT_BUILD_BLOCK + threadIdx.x);
+// the clusters of the first round: the triangles in Morton order
+__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_ploc_init(uint32_t n, const uint32_t* __restrict__ vals, const PtBox6* __restrict__ tri_box,
+                                                              uint32_t tri_first, uint32_t* __restrict__ items, uint32_t* __restrict__ cid,
+                                                              PtBox6* __restrict__ cbox) {
+    uint32_t k = blockIdx.x * PT_BUILD_BLOCK + threadIdx.x;
     if (k >= n) return;
     items[k] = tri_first + vals[k];
-    float box[6];
-    for (int c = 0; c < 6; c++) box[c] = leaf_box[6 * (size_t)vals[k] + c];
-    uint32_t me = (uint32_t)k | PT_LBVH_LEAF;
-    uint32_t p = leaf_parent[k];
-    while (p != PT_LBVH_NONE) {
-        // publish nothing yet: the first thread to arrive leaves, the second finds the sibling's box complete
-        if (atomicAdd(&arrived[p], 1u) == 0u) return;
-        uint32_t c0 = child[2 * p], c1 = child[2 * p + 1];
-        uint32_t sib = c0 == me ? c1 : c0;
-        float other[6];
-        if (sib & PT_LBVH_LEAF) {
-            for (int c = 0; c < 6; c++) other[c] = leaf_box[6 * (size_t)vals[sib & ~PT_LBVH_LEAF] + c];
-        } else {
-            for (int c = 0; c < 6; c++) other[c] = pt_load_coherent(node_box + 6 * (size_t)sib + c);
-        }
-        for (int c = 0; c < 3; c++) { box[c] = fminf(box[c], other[c]); box[3 + c] = fmaxf(box[3 + c], other[3 + c]); }
-        for (int c = 0; c < 6; c++) node_box[6 * (size_t)p + c] = box[c];
-        __threadfence();  // the box is visible before the parent's counter moves
-        me = p;
-        p = node_parent[p];
-    }
+    cid[k] = k | PT_PLOC_LEAF;
+    cbox[k] = tri_box[vals[k]];
 }
 
-__device__ __forceinline__ void pt_emit_child(uint32_t c, const uint32_t* __restrict__ range, const uint32_t* __restrict__ vals,
-                                              const float* __restrict__ leaf_box, const float* __restrict__ node_box, int max_leaf,
-                                              uint32_t node_base, uint32_t item_base, uint32_t* ref, float* lo, float* hi) {
-    const float* b;
-    if (c & PT_LBVH_LEAF) {
-        uint32_t k = c & ~PT_LBVH_LEAF;
-        *ref = PT_REF_LEAF | ((item_base + k) << 3);  // one triangle
-        b = leaf_box + 6 * (size_t)vals[k];
-    } else {
-        uint32_t first = range[2 * c], count = range[2 * c + 1] - first + 1u;
-        *ref = count <= (uint32_t)max_leaf ? (PT_REF_LEAF | ((item_base + first) << 3) | (count - 1u)) : node_base + c;
-        b = node_box + 6 * (size_t)c;
-    }
-    for (int k = 0; k < 3; k++) { lo[k] = b[k]; hi[k] = b[3 + k]; }
+__device__ __forceinline__ float pt_union_area(const PtBox6& a, const PtBox6& b) {
+    float dx = fmaxf(a.v[3], b.v[3]) - fminf(a.v[0], b.v[0]);
+    float dy = fmaxf(a.v[4], b.v[4]) - fminf(a.v[1], b.v[1]);
+    float dz = fmaxf(a.v[5], b.v[5]) - fminf(a.v[2], b.v[2]);
+    return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_lbvh_emit(int n, const uint32_t* __restrict__ child, const uint32_t* __restrict__ range,
-                                                              const uint32_t* __restrict__ vals, const float* __restrict__ leaf_box,
-                                                              const float* __restrict__ node_box, int max_leaf, uint32_t node_base,
-                                                              uint32_t item_base, PtBvhNode* __restrict__ nodes) {
-    int i = (int)(blockIdx.x * PT_BUILD_BLOCK + threadIdx.x);
-    if (i >= n - 1) return;
-    PtBvhNode nd;
-    memset(&nd, 0, sizeof nd);
-    if (range[2 * i + 1] - range[2 * i] + 1u > (uint32_t)max_leaf) {  // smaller subtrees are leaves of their parents: their nodes stay unused
-        pt_emit_child(child[2 * i], range, vals, leaf_box, node_box, max_leaf, node_base, item_base, &nd.child0, nd.lo0, nd.hi0);
-        pt_emit_child(child[2 * i + 1], range, vals, leaf_box, node_box, max_leaf, node_base, item_base, &nd.child1, nd.lo1, nd.hi1);
-    } else {
-        nd.child0 = nd.child1 = PT_REF_EMPTY;
+__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_ploc_nearest(uint32_t m, int radius, const PtBox6* __restrict__ cbox, uint32_t* __restrict__ nearest) {
+    uint32_t i = blockIdx.x * PT_BUILD_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const PtBox6 me = cbox[i];
+    int lo = (int)i - radius, hi = (int)i + radius;
+    if (lo < 0) lo = 0;
+    if (hi > (int)m - 1) hi = (int)m - 1;
+    float best = INFINITY;
+    uint32_t best_j = i;
+    for (int j = lo; j <= hi; j++) {
+        if (j == (int)i) continue;
+        float a = pt_union_area(me, cbox[j]);
+        if (a < best || best_j == i) { best = a; best_j = (uint32_t)j; }  // the first of equal areas; any j if every area is NaN / inf
     }
-    nodes[node_base + (uint32_t)i] = nd;
+    nearest[i] = best_j;
 }
 
-// One thread per inner node and per leaf: report the ones that are treelet roots (subtree of <= limit
-// triangles under a parent with more), with their packed reference and box.
-struct PtTreelet {
-    uint32_t ref;
-    float box[6];
+struct PtPlocOut {  // everything pt_ploc_merge writes for the finished tree
+    PtBvhNode* nodes;       // d_nodes + node_base
+    uint32_t* items;        // d_items + item_base: [0, n) single triangles in Morton order, then max_leaf slots per node
+    uint32_t* leaf_count;   // per node: triangles if the node was turned into a leaf, else 0
+    uint32_t* node_parent;  // per node
+    uint32_t* leaf_parent;  // per sorted triangle
+    uint32_t* counter;      // next free node
+    uint32_t node_base, item_base, n;
+    int max_leaf;
 };
-__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_lbvh_treelets(int n, const uint32_t* __restrict__ range, const uint32_t* __restrict__ node_parent,
-                                                                  const uint32_t* __restrict__ leaf_parent, const uint32_t* __restrict__ vals,
-                                                                  const float* __restrict__ leaf_box, const float* __restrict__ node_box, uint32_t limit,
-                                                                  int max_leaf, uint32_t node_base, uint32_t item_base, uint32_t capacity,
-                                                                  uint32_t* __restrict__ count, PtTreelet* __restrict__ out) {
-    int g = (int)(blockIdx.x * PT_BUILD_BLOCK + threadIdx.x);
-    if (g >= 2 * n - 1) return;
-    uint32_t parent, size, ref;
-    const float* b;
-    if (g < n - 1) {  // inner node g
-        parent = node_parent[g];
-        uint32_t first = range[2 * g];
-        size = range[2 * g + 1] - first + 1u;
-        ref = size <= (uint32_t)max_leaf ? (PT_REF_LEAF | ((item_base + first) << 3) | (size - 1u)) : node_base + (uint32_t)g;
-        b = node_box + 6 * (size_t)g;
-    } else {  // leaf
-        uint32_t k = (uint32_t)(g - (n - 1));
-        parent = leaf_parent[k];
-        size = 1u;
-        ref = PT_REF_LEAF | ((item_base + k) << 3);
-        b = leaf_box + 6 * (size_t)vals[k];
-    }
-    if (size > limit || parent == PT_LBVH_NONE) return;
-    if (range[2 * parent + 1] - range[2 * parent] + 1u <= limit) return;  // inside a treelet, not its root
-    uint32_t slot = atomicAdd(count, 1u);
-    if (slot >= capacity) return;
-    out[slot].ref = ref;
-    for (int c = 0; c < 6; c++) out[slot].box[c] = b[c];
+
+// number of triangles if `id` is a leaf of the final tree (a triangle or a collapsed node), else 0; *first = its items
+__device__ __forceinline__ uint32_t pt_ploc_leaf_items(const PtPlocOut& o, uint32_t id, uint32_t* first) {
+    if (id & PT_PLOC_LEAF) { *first = id & ~PT_PLOC_LEAF; return 1u; }
+    uint32_t c = o.leaf_count[id];
+    *first = o.n + (uint32_t)o.max_leaf * id;
+    return c;
+}
+__device__ __forceinline__ uint32_t pt_ploc_ref(const PtPlocOut& o, uint32_t id) {
+    uint32_t first, c = pt_ploc_leaf_items(o, id, &first);
+    return c ? (PT_REF_LEAF | ((o.item_base + first) << 3) | (c - 1u)) : o.node_base + id;
 }
 
-// longest chain of inner nodes from a leaf up to (and including) its treelet's root, + 1
-__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_lbvh_depth(int n, const uint32_t* __restrict__ range, const uint32_t* __restrict__ node_parent,
-                                                               const uint32_t* __restrict__ leaf_parent, uint32_t limit, int* depth) {
-    int k = (int)(blockIdx.x * PT_BUILD_BLOCK + threadIdx.x);
+__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_ploc_merge(uint32_t m, const uint32_t* __restrict__ nearest, const uint32_t* __restrict__ cid,
+                                                               const PtBox6* __restrict__ cbox, uint32_t* __restrict__ cid_out,
+                                                               PtBox6* __restrict__ cbox_out, uint32_t* __restrict__ keep, PtPlocOut o) {
+    uint32_t i = blockIdx.x * PT_BUILD_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    uint32_t j = nearest[i];
+    bool mutual = j != i && nearest[j] == i;
+    if (!mutual) { cid_out[i] = cid[i]; cbox_out[i] = cbox[i]; keep[i] = 1u; return; }
+    if (i > j) { keep[i] = 0u; return; }
+    const uint32_t a = cid[i], b = cid[j];
+    const PtBox6 ba = cbox[i], bb = cbox[j];
+    const uint32_t node = atomicAdd(o.counter, 1u);
+    uint32_t fa, fb, ca = pt_ploc_leaf_items(o, a, &fa), cb = pt_ploc_leaf_items(o, b, &fb);
+    if (ca && cb && ca + cb <= (uint32_t)o.max_leaf) {  // a leaf of ca + cb triangles: gather them in the node's own slot
+        uint32_t dst = o.n + (uint32_t)o.max_leaf * node;
+        for (uint32_t k = 0; k < ca; k++) o.items[dst + k] = o.items[fa + k];
+        for (uint32_t k = 0; k < cb; k++) o.items[dst + ca + k] = o.items[fb + k];
+        o.leaf_count[node] = ca + cb;
+    } else {
+        PtBvhNode nd;
+        for (int k = 0; k < 3; k++) { nd.lo0[k] = ba.v[k]; nd.hi0[k] = ba.v[3 + k]; nd.lo1[k] = bb.v[k]; nd.hi1[k] = bb.v[3 + k]; }
+        nd.child0 = pt_ploc_ref(o, a);
+        nd.child1 = pt_ploc_ref(o, b);
+        nd.pad[0] = nd.pad[1] = 0u;
+        o.nodes[node] = nd;
+        o.leaf_count[node] = 0u;
+    }
+    if (a & PT_PLOC_LEAF) o.leaf_parent[a & ~PT_PLOC_LEAF] = node; else o.node_parent[a] = node;
+    if (b & PT_PLOC_LEAF) o.leaf_parent[b & ~PT_PLOC_LEAF] = node; else o.node_parent[b] = node;
+    o.node_parent[node] = PT_PLOC_NONE;
+    PtBox6 u;
+    for (int k = 0; k < 3; k++) { u.v[k] = fminf(ba.v[k], bb.v[k]); u.v[3 + k] = fmaxf(ba.v[3 + k], bb.v[3 + k]); }
+    cid_out[i] = node;
+    cbox_out[i] = u;
+    keep[i] = 1u;
+}
+
+__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_ploc_compact(uint32_t m, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos,
+                                                                 const uint32_t* __restrict__ cid_in, const PtBox6* __restrict__ cbox_in,
+                                                                 uint32_t* __restrict__ cid, PtBox6* __restrict__ cbox, uint32_t* __restrict__ m_out) {
+    uint32_t i = blockIdx.x * PT_BUILD_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    if (keep[i]) { cid[pos[i]] = cid_in[i]; cbox[pos[i]] = cbox_in[i]; }
+    if (i == m - 1) *m_out = pos[i] + keep[i];
+}
+
+// inner nodes on the path from a triangle to the root, + 1
+__global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_ploc_depth(uint32_t n, const uint32_t* __restrict__ node_parent, const uint32_t* __restrict__ leaf_parent,
+                                                               const uint32_t* __restrict__ leaf_count, int* depth) {
+    uint32_t k = blockIdx.x * PT_BUILD_BLOCK + threadIdx.x;
     int d = 0;
     if (k < n) {
         d = 1;
-        for (uint32_t p = leaf_parent[k]; p != PT_LBVH_NONE && range[2 * p + 1] - range[2 * p] + 1u <= limit; p = node_parent[p]) d++;
+        for (uint32_t p = leaf_parent[k]; p != PT_PLOC_NONE; p = node_parent[p]) d += leaf_count[p] ? 0 : 1;
     }
     for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
     if ((threadIdx.x & 63) == 0) atomicMax(depth, d);
@@ -256,30 +230,34 @@ hipError_t pt_device_build_mesh_tree(const double* d_tri_v, uint32_t tri_first, 
                                      PtDeviceBuildResult* out) {
     Arena arena;
     if (n < 2 || max_leaf < 1 || max_leaf > 8 || n <= (uint32_t)max_leaf) return hipErrorInvalidValue;
-    size_t sort_bytes = 0;
+    size_t sort_bytes = 0, scan_bytes = 0;
     PT_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
                                      (uint32_t*)nullptr, (size_t)n, 0u, 63u, stream));
+    PT_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    const size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
     // one allocation for every temporary
-    size_t need = 4096 + sort_bytes + (size_t)n * (8 + 8 + 4 + 4 + 24 + 24 + 8 + 8 + 4 + 4 + 4 + sizeof(PtTreelet)) + 256 * 20;
+    size_t need = 8192 + tmp_bytes + (size_t)n * (8 + 8 + 4 + 4 + 24 + 3 * 24 + 3 * 4 + 4 + 4 + 4 + 4 + 4 + 4);
     PT_TRY(hipMalloc((void**)&arena.base, need));
     arena.cap = need;
     auto* keys_in = arena.take<unsigned long long>(n);
     auto* keys = arena.take<unsigned long long>(n);
     auto* vals_in = arena.take<uint32_t>(n);
     auto* vals = arena.take<uint32_t>(n);
-    auto* leaf_box = arena.take<float>(6 * (size_t)n);
-    auto* node_box = arena.take<float>(6 * (size_t)n);
-    auto* child = arena.take<uint32_t>(2 * (size_t)n);
-    auto* range = arena.take<uint32_t>(2 * (size_t)n);
+    auto* tri_box = arena.take<PtBox6>(n);
+    PtBox6* cbox[3] = {arena.take<PtBox6>(n), arena.take<PtBox6>(n), arena.take<PtBox6>(n)};  // current, merged (with gaps), next
+    uint32_t* cid[3] = {arena.take<uint32_t>(n), arena.take<uint32_t>(n), arena.take<uint32_t>(n)};
+    auto* nearest = arena.take<uint32_t>(n);
+    auto* keep = arena.take<uint32_t>(n);
+    auto* pos = arena.take<uint32_t>(n);
+    auto* leaf_count = arena.take<uint32_t>(n);
     auto* node_parent = arena.take<uint32_t>(n);
     auto* leaf_parent = arena.take<uint32_t>(n);
-    auto* arrived = arena.take<uint32_t>(n);
-    auto* depth = arena.take<int>(1);
-    auto* counter = arena.take<uint32_t>(1);
-    const uint32_t top_capacity = n;
-    auto* treelets = arena.take<PtTreelet>(top_capacity);
-    void* sort_tmp = arena.take<char>(sort_bytes);
+    auto* scalars = arena.take<uint32_t>(4);  // [0] next node, [1] clusters left, [2] depth
+    void* tmp = arena.take<char>(tmp_bytes);
     if (arena.used > arena.cap) { hipFree(arena.base); return hipErrorOutOfMemory; }
+
+    int radius = PT_PLOC_RADIUS;
+    if (const char* e = getenv("PORTRAYER_PLOC_RADIUS")) radius = std::min(std::max(atoi(e), 1), 128);
 
     hipEvent_t e0, e1;
     PT_TRY(hipEventCreate(&e0));
@@ -287,62 +265,49 @@ hipError_t pt_device_build_mesh_tree(const double* d_tri_v, uint32_t tri_first, 
     PT_TRY(hipEventRecord(e0, stream));
     double inv[3];
     for (int k = 0; k < 3; k++) inv[k] = hi[k] > lo[k] ? 1.0 / (hi[k] - lo[k]) : 0.0;
-    const unsigned blocks = (n + PT_BUILD_BLOCK - 1) / PT_BUILD_BLOCK;
-    PT_TRY(hipMemsetAsync(arrived, 0, (size_t)n * 4, stream));
-    PT_TRY(hipMemsetAsync(depth, 0, 4, stream));
-    PT_TRY(hipMemsetAsync(counter, 0, 4, stream));
-    hipLaunchKernelGGL(pt_lbvh_prepare, dim3(blocks), dim3(PT_BUILD_BLOCK), 0, stream, d_tri_v, tri_first, n, lo[0], lo[1], lo[2], inv[0], inv[1], inv[2], pad,
-                       keys_in, vals_in, leaf_box);
+    auto blocks = [](uint32_t count) { return dim3((count + PT_BUILD_BLOCK - 1) / PT_BUILD_BLOCK); };
+    PT_TRY(hipMemsetAsync(scalars, 0, 16, stream));
+    hipLaunchKernelGGL(pt_ploc_prepare, blocks(n), dim3(PT_BUILD_BLOCK), 0, stream, d_tri_v, tri_first, n, lo[0], lo[1], lo[2], inv[0], inv[1], inv[2], pad,
+                       keys_in, vals_in, tri_box);
     PT_TRY(hipGetLastError());
-    PT_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_in, keys, vals_in, vals, (size_t)n, 0u, 63u, stream));
-    hipLaunchKernelGGL(pt_lbvh_hierarchy, dim3(blocks), dim3(PT_BUILD_BLOCK), 0, stream, keys, (int)n, child, range, node_parent, leaf_parent);
+    PT_TRY(rocprim::radix_sort_pairs(tmp, sort_bytes, keys_in, keys, vals_in, vals, (size_t)n, 0u, 63u, stream));
+    hipLaunchKernelGGL(pt_ploc_init, blocks(n), dim3(PT_BUILD_BLOCK), 0, stream, n, vals, tri_box, tri_first, d_items + item_base, cid[0], cbox[0]);
     PT_TRY(hipGetLastError());
-    hipLaunchKernelGGL(pt_lbvh_refit, dim3(blocks), dim3(PT_BUILD_BLOCK), 0, stream, (int)n, vals, leaf_box, child, node_parent, leaf_parent, node_box, arrived,
-                       tri_first, d_items + item_base);
-    PT_TRY(hipGetLastError());
-    hipLaunchKernelGGL(pt_lbvh_emit, dim3(blocks), dim3(PT_BUILD_BLOCK), 0, stream, (int)n, child, range, vals, leaf_box, node_box, max_leaf, node_base, item_base,
-                       d_nodes);
-    PT_TRY(hipGetLastError());
-    // ---- top tree over the treelets
-    uint32_t limit = PT_TREELET;
-    if (const char* e = getenv("PORTRAYER_TREELET")) limit = (uint32_t)std::max(1, atoi(e));
-    if (limit >= n) limit = n - 1;  // the root itself is never a treelet
-    hipLaunchKernelGGL(pt_lbvh_treelets, dim3((2 * n - 1 + PT_BUILD_BLOCK - 1) / PT_BUILD_BLOCK), dim3(PT_BUILD_BLOCK), 0, stream, (int)n, range, node_parent,
-                       leaf_parent, vals, leaf_box, node_box, limit, max_leaf, node_base, item_base, top_capacity, counter, treelets);
-    PT_TRY(hipGetLastError());
-    hipLaunchKernelGGL(pt_lbvh_depth, dim3(blocks), dim3(PT_BUILD_BLOCK), 0, stream, (int)n, range, node_parent, leaf_parent, limit, depth);
+
+    PtPlocOut o;
+    o.nodes = d_nodes + node_base; o.items = d_items + item_base; o.leaf_count = leaf_count; o.node_parent = node_parent; o.leaf_parent = leaf_parent;
+    o.counter = scalars; o.node_base = node_base; o.item_base = item_base; o.n = n; o.max_leaf = max_leaf;
+    uint32_t m = n;
+    int rounds = 0;
+    while (m > 1) {
+        if (++rounds > 4096) { hipFree(arena.base); return hipErrorLaunchFailure; }  // every round merges at least the closest pair
+        hipLaunchKernelGGL(pt_ploc_nearest, blocks(m), dim3(PT_BUILD_BLOCK), 0, stream, m, radius, cbox[0], nearest);
+        hipLaunchKernelGGL(pt_ploc_merge, blocks(m), dim3(PT_BUILD_BLOCK), 0, stream, m, nearest, cid[0], cbox[0], cid[1], cbox[1], keep, o);
+        PT_TRY(hipGetLastError());
+        PT_TRY(rocprim::exclusive_scan(tmp, scan_bytes, keep, pos, 0u, (size_t)m, rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(pt_ploc_compact, blocks(m), dim3(PT_BUILD_BLOCK), 0, stream, m, keep, pos, cid[1], cbox[1], cid[2], cbox[2], scalars + 1);
+        PT_TRY(hipGetLastError());
+        PT_TRY(hipMemcpyAsync(&m, scalars + 1, 4, hipMemcpyDeviceToHost, stream));
+        PT_TRY(hipStreamSynchronize(stream));
+        std::swap(cid[0], cid[2]);
+        std::swap(cbox[0], cbox[2]);
+    }
+    hipLaunchKernelGGL(pt_ploc_depth, blocks(n), dim3(PT_BUILD_BLOCK), 0, stream, n, node_parent, leaf_parent, leaf_count, (int*)(scalars + 2));
     PT_TRY(hipGetLastError());
     PT_TRY(hipEventRecord(e1, stream));
-    int h_depth = 0;
-    uint32_t n_treelets = 0;
-    PT_TRY(hipMemcpyAsync(&h_depth, depth, 4, hipMemcpyDeviceToHost, stream));
-    PT_TRY(hipMemcpyAsync(&n_treelets, counter, 4, hipMemcpyDeviceToHost, stream));
+    uint32_t h[3] = {0, 0, 0}, root = 0;
+    PT_TRY(hipMemcpyAsync(h, scalars, 12, hipMemcpyDeviceToHost, stream));
+    PT_TRY(hipMemcpyAsync(&root, cid[0], 4, hipMemcpyDeviceToHost, stream));
     PT_TRY(hipStreamSynchronize(stream));
-    if (n_treelets < 2 || n_treelets > top_capacity) { hipFree(arena.base); return hipErrorInvalidValue; }  // cannot happen for n > limit >= 1 (capacity = n)
-    std::vector<PtTreelet> tl(n_treelets);
-    PT_TRY(hipMemcpy(tl.data(), treelets, (size_t)n_treelets * sizeof(PtTreelet), hipMemcpyDeviceToHost));
-    std::sort(tl.begin(), tl.end(), [](const PtTreelet& a, const PtTreelet& b) { return a.ref < b.ref; });  // the atomic hands slots out in any order
-    std::vector<PtBuildBox> boxes(n_treelets);
-    for (uint32_t i = 0; i < n_treelets; i++)
-        for (int k = 0; k < 3; k++) { boxes[i].lo[k] = tl[i].box[k]; boxes[i].hi[k] = tl[i].box[3 + k]; }
-    std::vector<PtBvhNode> top;
-    std::vector<uint32_t> top_items;
-    PtBvhRef top_root = pt_bvh_build(boxes.data(), nullptr, n_treelets, 1, top, top_items);
-    const uint32_t top_base = node_base + (n - 1);
-    auto patch = [&](uint32_t ref) -> uint32_t {  // one-item leaves of the top tree become references to the treelets' roots
-        if (ref & PT_REF_LEAF) return tl[top_items[(ref & ~PT_REF_LEAF) >> 3]].ref;
-        return top_base + ref;
-    };
-    for (PtBvhNode& nd : top) { nd.child0 = patch(nd.child0); nd.child1 = patch(nd.child1); }
-    PT_TRY(hipMemcpy(d_nodes + top_base, top.data(), top.size() * sizeof(PtBvhNode), hipMemcpyHostToDevice));
     float ms = 0.0f;
     PT_TRY(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     hipFree(arena.base);
-    out->root = patch(top_root.child);
-    out->depth = h_depth + top_root.depth;
+    if (h[0] != n - 1 || (root & PT_PLOC_LEAF)) return hipErrorLaunchFailure;  // a binary tree over n leaves has n - 1 nodes
+    out->root = node_base + root;  // n > max_leaf: the root is never a leaf
+    out->depth = (int)h[2];
     out->ms = ms;
-    out->n_treelets = n_treelets;
+    out->rounds = rounds;
     return hipSuccess;
 }

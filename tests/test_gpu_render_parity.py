@@ -304,6 +304,39 @@ def test_large_synthetic_scene_matches_oracle(oracle, host, H, name, size):
 
 
 # ---------------------------------------------------------------------------------------------------
+# device-side tree build (pt_build.hip): the tree only finds candidates, so an image
+# rendered over device-built mesh trees equals the one over host-built trees bit for bit
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["macho-cows", "entering-the-mirror-dimension"])
+def test_device_built_trees_give_the_same_image(host, H, monkeypatch, name):
+    scene = host.Scene.example(name)
+    w, h = 320, 180
+    out = {}
+    for build in ("host", "device"):
+        monkeypatch.setenv("PORTRAYER_BUILD", build)
+        r = host.Renderer(scene, H.TRAVERSE_FLAT)
+        rgb, linear, st = r.render(scene.camera, w, h, default_background(w, h), samples=4, seed=3, sample_mode=H.SAMPLE_RNG, stats=True)
+        out[build] = (rgb, linear, st)
+        r.close()
+    assert np.array_equal(out["host"][0], out["device"][0])
+    assert np.array_equal(out["host"][1], out["device"][1])
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert out["host"][2][k] == out["device"][2][k], k
+
+
+def test_device_build_of_a_large_mesh_matches_oracle(oracle, host, H, monkeypatch):
+    from example_scenes import SYNTHETIC
+    scene, cam, _ = SYNTHETIC["big-soup"](3)  # 27 cows baked into one 156,708-triangle mesh: above the automatic threshold
+    monkeypatch.delenv("PORTRAYER_BUILD", raising=False)
+    w, h = 64, 36
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_FLAT)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), stats=True)
+    ref = oracle.render(scene, cam, w, h, mode=oracle.MODE_FLAT)
+    assert st["hits"] == ref.stats["hits"] > 0 and st["shadow"] == ref.stats["shadow"]
+    assert np.array_equal(rgb, ref.rgb)
+
+
+# ---------------------------------------------------------------------------------------------------
 # fuzz: thin / huge / tiny / touching primitives (tests/fuzz_gpu_parity.py runs the long version:
 # 250 seeds x {random, extreme} x {flat, kd} = 1000 renders, 0 differing pixels on MI355X)
 # ---------------------------------------------------------------------------------------------------
