@@ -20,6 +20,14 @@
 
 #define PT_NO_HIT 0xFFFFFFFFu
 
+// experiment (profiles/wavecount.sh): one count per WAVEFRONT pass through a place, kept in a counter the
+// scene does not otherwise use, to compare with the per-lane counts (lane occupancy of that place)
+#ifdef PT_WAVE_COUNTS
+#define PT_WAVE_COUNT(field) do { if (STATS && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt->field++; } while (0)
+#else
+#define PT_WAVE_COUNT(field) do { } while (0)
+#endif
+
 struct PtHit {
     double t;       // ray parameter of the best hit so far; doubles as the exclusive range end
     uint32_t node;  // flat node index, PT_NO_HIT when nothing was hit
@@ -113,6 +121,7 @@ PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, co
         while (!(cur & PT_REF_LEAF)) {
             const PtBvhNode& n = nodes[cur];
             if (STATS) cnt->n_inner++;
+            PT_WAVE_COUNT(n_tri);
             // tmax rounded up: (float) rounds to nearest, one more relative step covers it (inf stays inf)
             float tm = (float)tmax; tm = tm + fabsf(tm) * 2.4e-7f;
             float t0, t1;
@@ -134,6 +143,7 @@ PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, co
             }
         }
         if (STATS) cnt->n_leaf++;
+        PT_WAVE_COUNT(n_bbox);
         if (leaf((cur & ~PT_REF_LEAF) >> 3, (cur & 7u) + 1u, sp)) return true;
         if (sp == sp0) return false;
         cur = pt_pop(stk, sp);
