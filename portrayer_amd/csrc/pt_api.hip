@@ -224,6 +224,7 @@ struct pt_context {
     std::string err;
     PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh_items, kd, kd_items;
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, mkd, mkd_items;
+    PtBuf node_box, kd_box;
     PtBuf frames, accum, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
     PtSceneView view;
     bool have_scene = false;
@@ -289,7 +290,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc};
+                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -571,6 +572,38 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     }
 
     int rc;
+    std::vector<float> node_box32;
+    if (traverse == PT_TRAVERSE_KD) {
+        node_box32.resize(6 * kdi.size());  // in leaf-item order: the walk reads a leaf's boxes one after the other
+        for (size_t j = 0; j < kdi.size(); j++)
+            for (int k = 0; k < 3; k++) {
+                node_box32[6 * j + k] = pt_bvh_detail::round_down(node_box[kdi[j]].lo[k]);
+                node_box32[6 * j + 3 + k] = pt_bvh_detail::round_up(node_box[kdi[j]].hi[k]);
+            }
+    }
+    std::vector<float> kd_box32;
+    if (traverse == PT_TRAVERSE_KD) {  // children follow their parents in the linearised tree (pre-order): one backward sweep
+        kd_box32.assign(6 * kdn.size(), 0.0f);
+        for (size_t i = kdn.size(); i-- > 0;) {
+            float* b = &kd_box32[6 * i];
+            const PtKdNode& k = kdn[i];
+            for (int r = 0; r < 3; r++) { b[r] = (float)PT_BOX_LIMIT; b[3 + r] = -(float)PT_BOX_LIMIT; }  // empty
+            if (k.axis < 0) {
+                for (int32_t j = 0; j < k.count; j++)
+                    for (int r = 0; r < 3; r++) {
+                        b[r] = std::min(b[r], node_box32[6 * (size_t)(k.first + j) + r]);
+                        b[3 + r] = std::max(b[3 + r], node_box32[6 * (size_t)(k.first + j) + 3 + r]);
+                    }
+            } else if ((size_t)k.front > i && (size_t)k.back > i) {
+                for (int r = 0; r < 3; r++) {
+                    b[r] = std::min(kd_box32[6 * (size_t)k.front + r], kd_box32[6 * (size_t)k.back + r]);
+                    b[3 + r] = std::max(kd_box32[6 * (size_t)k.front + 3 + r], kd_box32[6 * (size_t)k.back + 3 + r]);
+                }
+            } else {  // not in pre-order: no culling at this node
+                for (int r = 0; r < 3; r++) { b[r] = -(float)PT_BOX_LIMIT; b[3 + r] = (float)PT_BOX_LIMIT; }
+            }
+        }
+    }
     lap("scene tree");
     if ((rc = pt_upload(c, c->tri_v, tri_v))) return rc;
     {   // tree arrays: the host-built part first, then room for the device-built mesh trees
@@ -598,7 +631,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     }
     if ((rc = pt_upload(c, c->inv, inv)) || (rc = pt_upload(c, c->fwd, fwd)) || (rc = pt_upload(c, c->nrm, nrm)) ||
         (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
-        (rc = pt_upload(c, c->meshes, meshes)) ||
+        (rc = pt_upload(c, c->meshes, meshes)) || (rc = pt_upload(c, c->node_box, node_box32)) || (rc = pt_upload(c, c->kd_box, kd_box32)) ||
         (rc = pt_upload(c, c->kd, kdn)) || (rc = pt_upload(c, c->kd_items, kdi)) || (rc = pt_upload(c, c->mkd, mkd)) ||
         (rc = pt_upload(c, c->mkd_items, mkd_items)))
         return rc;
@@ -678,6 +711,9 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.tlas_root = tlas.child; v.pad0 = 0;
     v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
     v.kd_extent = kd_extent;
+    v.node_box = traverse == PT_TRAVERSE_KD && !kdi.empty() ? (const float*)c->node_box.p : nullptr;
+    v.kd_box = traverse == PT_TRAVERSE_KD ? (const float*)c->kd_box.p : nullptr;
+    if (getenv("PORTRAYER_KD_NO_CULL")) v.kd_box = v.node_box = nullptr;  // experiment: the reference's walk as it is
     v.mkd = (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;
     v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
     // mesh-heavy scenes spend > 90 % of the wave cycles in the tree walk and gain from a 4th wave (big-soup 2.46 -> 2.75 Gray/s);

@@ -74,6 +74,8 @@ struct PtSceneView {
     uint32_t tlas_root, pad0;
     const PtKdNode* kd;
     const uint32_t* kd_items;
+    const float* kd_box;     // KD mode: per k-d node, the union of the boxes of everything below it (6 f32, rounded outward); else null
+    const float* node_box;   // KD mode: per kd_items entry, that node's padded world box as 6 f32 rounded outward (leaf pre-cull in pt_trace_kd); else null
     double kd_extent;  // bounding_box.rs:95-99: squared diagonal of the root bounds
     int32_t mode;
     int32_t stack_cap;  // entries per lane in the traversal stack
@@ -98,5 +100,5 @@ struct PtCamera {  // camera.rs:17-31, built on the host (look_at inverse, tan)
 // Per-lane counters, SURVEY §8(d) ray accounting
 struct PtCounters {
     unsigned long long primary, shadow, reflect, refract, depth11_skipped, hits;
-    unsigned long long n_inner, n_leaf, n_analytic, n_tri, n_bbox, kd_plane_miss, stack_overflow;
+    unsigned long long n_inner, n_leaf, n_analytic, n_tri, n_bbox, kd_plane_miss, stack_overflow, kd_culled;
 };

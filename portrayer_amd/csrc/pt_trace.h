@@ -105,6 +105,19 @@ PT_HD bool pt_slab32(const float* lo, const float* hi, const PtRay32& q, float t
     return !(tn > tf);
 }
 
+// The same test against a segment [tmin, tmax] of the ray (both already rounded outward by the caller).
+PT_HD bool pt_slab32_segment(const float* lo, const float* hi, const PtRay32& q, float tmin, float tmax) {
+    float x0 = __builtin_fmaf(lo[0], q.ix, q.n0x), x1 = __builtin_fmaf(hi[0], q.ix, q.n1x);
+    float y0 = __builtin_fmaf(lo[1], q.iy, q.n0y), y1 = __builtin_fmaf(hi[1], q.iy, q.n1y);
+    float z0 = __builtin_fmaf(lo[2], q.iz, q.n0z), z1 = __builtin_fmaf(hi[2], q.iz, q.n1z);
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    const float w = 9.6e-7f;
+    tn = fmaxf(__builtin_fmaf(fabsf(tn), -w, tn), tmin);
+    tf = fminf(__builtin_fmaf(fabsf(tf), w, tf), tmax);
+    return !(tn > tf);
+}
+
 // Generic walk of the build's two-child tree, "while-while": every lane first descends through inner
 // nodes until it holds a leaf (or has nothing left), and only then do the lanes test their leaves
 // together — the leaf work (f64 primitive tests) is the expensive part and should run with as many
@@ -408,14 +421,32 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
     int sp = 0;
     int32_t cur = 0;
     const double extent = sc.kd_extent;
+    const PtRay32 q = pt_ray32(ray);
     for (;;) {
         const PtKdNode n = sc.kd[cur];
-        if (n.axis < 0) {  // Leaf: ray.rs:87-99 fold over the leaf's nodes, reference order, strict ends
+        // The ray's segment [start, end), rounded outward, against conservative f32 boxes: first the union of
+        // everything below this tree node - a subtree the segment does not reach reports no hit, which is all
+        // the reference would find out by walking it - then, in a leaf, each referenced node's own box.
+        float seg0 = (float)start, seg1 = (float)end;
+        seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
+        if (sc.kd_box && !pt_slab32_segment(sc.kd_box + 6 * (size_t)cur, sc.kd_box + 6 * (size_t)cur + 3, q, seg0, seg1)) {
+            if (STATS) cnt->kd_culled++;
+        } else if (n.axis < 0) {  // Leaf: ray.rs:87-99 fold over the leaf's nodes, reference order, strict ends
             if (STATS) cnt->n_leaf++;
             bool found = false;
+            // The reference's tree puts a node into every leaf its box touches (6.8 references per node on
+            // big-scene) and tests all of them. A node whose (padded, outward-rounded) world box the ray's
+            // segment [start, end) does not reach cannot report a hit in that range, so it is skipped before
+            // the f64 test: same answers, 60 instead of 2 exact tests per ray saved.
             for (int32_t i = 0; i < n.count; i++) {
+                const uint32_t item = sc.kd_items[n.first + i];
+                if (sc.node_box) {
+                    const float* b = sc.node_box + 6 * (size_t)(n.first + i);
+                    if (STATS) cnt->n_bbox++;
+                    if (!pt_slab32_segment(b, b + 3, q, seg0, seg1)) continue;
+                }
                 PtHit lb; lb.t = end; lb.node = PT_NO_HIT; lb.sub = 0;
-                if (pt_test_node<STATS>(sc, sc.kd_items[n.first + i], ray, start, lb, any, stk, sp, cnt)) {
+                if (pt_test_node<STATS>(sc, item, ray, start, lb, any, stk, sp, cnt)) {
                     best = lb; end = lb.t; found = true;
                     if (any) return true;
                 }
