@@ -3,7 +3,8 @@
 Scene constants are taken from the reference's scene scripts (data, not code):
   examples/single-triangle.rs:17-58, examples/primitives-simple.rs:17-76,
   examples/macho-cows.rs:17-128, examples/entering-the-mirror-dimension.rs:17-188,
-  examples/big-scene.rs:26-109.
+  examples/big-scene.rs:26-109, examples/smooth-shading.rs:17-100, examples/glossy-reflection.rs:17-87,
+  examples/soft-shadows.rs:17-95.
 The product has its own C++ transliteration of the same scripts (examples/*.cpp); the tests check
 that both produce identical node matrices.
 """
@@ -143,6 +144,68 @@ def big_scene(n: int = 10, prims=None):
                   ambient=(0.3, 0.3, 0.3))
     cam = Camera(eye=(0.0, 0.0, 1200.0), center=(0.0, 0.0, 0.0), fovy_degrees=50.0)
     return scene, cam, (1980, 1020)
+
+
+def smooth_shading():
+    mat_rock = Material(diffuse=(0.256361, 0.256361, 0.256361), specular=(0.6, 0.6, 0.6), shininess=50.0)
+    mat_cow = Material(diffuse=(0.692066, 0.477245, 0.293336), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    mat_monkey = Material(diffuse=(0.261829, 0.8, 0.310477), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    monkey, cow, flat_rock, smooth_rock = (load_mesh(f) for f in ("monkey.obj", "cow.obj", "flat_rock.obj", "smooth_rock.obj"))
+    scene = Scene(
+        root=Node.group([
+            Node.geo(Mesh(monkey), mat_monkey).rotated_y(to_radians(45.0)).translated((-1.904434, 1.4, 0.0)),
+            Node.geo(Mesh(cow), mat_cow).scaled(0.5).rotated_y(to_radians(-15.0)).translated((-4.2, 1.8, 4.0)),
+            Node.geo(Mesh(flat_rock), mat_rock).translated((-3.396987, -1.4, 2.286671)),
+            Node.geo(Mesh(monkey, smooth=True), mat_monkey).rotated_y(to_radians(-45.0)).translated((1.242585, 1.4, 0.0)),
+            Node.geo(Mesh(cow, smooth=True), mat_cow).scaled(0.5).rotated_y(to_radians(205.0)).translated((3.8, 1.8, 4.0)),
+            Node.geo(Mesh(smooth_rock, smooth=True), mat_rock).translated((3.271008, -1.406423, 2.372513)),
+        ]),
+        lights=[Light(position=(0.0, 5.0, 10.0), color=(0.9, 0.9, 0.9))],
+        ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(1.062382, 0.54746, 22.827951), center=(-0.813817, 0.424462, -8.112782), fovy_degrees=24.0)
+    return scene, cam, (910, 512)
+
+
+def glossy_reflection():
+    non_glossy_ball = Material(diffuse=(0.146505, 0.314666, 0.170564), specular=(0.3, 0.3, 0.3), shininess=100.0, reflectivity=0.4)
+    glossy_ball = Material(diffuse=(0.146505, 0.314666, 0.170564), specular=(0.3, 0.3, 0.3), shininess=100.0, reflectivity=0.4,
+                           glossy_side_length=2.0)
+    center_ball = Material(diffuse=(0.8, 0.0, 0.023362), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    table = Material(diffuse=(1.0, 0.6, 0.1), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    scene = Scene(
+        root=Node.group([
+            Node.geo(Sphere(), non_glossy_ball).translated((-1.1, 1.3, 0.0)),
+            Node.geo(Sphere(), glossy_ball).translated((1.1, 1.3, 0.0)),
+            Node.geo(Sphere(), center_ball).scaled(0.5).translated((0.0, 0.8, 1.8)),
+            Node.geo(Cube(), table).scaled((10.0, 0.6, 5.0)),
+        ]),
+        lights=[Light(position=(0.0, 6.0, 3.0), color=(0.9, 0.9, 0.9)), Light(position=(0.0, 1.0, 12.0), color=(0.7, 0.7, 0.7))],
+        ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.0, 2.562834, 8.863271), center=(0.0, -1.083779, -11.817695), fovy_degrees=20.0)
+    return scene, cam, (910, 512)
+
+
+def soft_shadows():
+    mat_cow = Material(diffuse=(0.37168, 0.236767, 0.692066), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    mat_wall_floor = Material(diffuse=(0.627459, 0.8, 0.589836), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    cow = load_mesh("cow.obj")
+    scene = Scene(
+        root=Node.group([
+            Node.geo(Plane(), mat_wall_floor).scaled(30.0),
+            Node.geo(Cube(), mat_wall_floor).scaled((0.2, 20.0, 20.0)).translated((0.0, 8.0, 8.0)),
+            Node.geo(Cube(), mat_wall_floor).scaled((30.0, 30.0, 0.4)).translated((0.0, 8.0, -2.0)),
+            Node.geo(Mesh(cow, smooth=True), mat_cow).scaled(0.5).rotated_y(to_radians(-15.0)).translated((-4.2, 1.8, 4.0)),
+            Node.geo(Mesh(cow, smooth=True), mat_cow).scaled(0.5).rotated_y(to_radians(195.0)).translated((4.2, 1.8, 4.0)),
+        ]),
+        lights=[Light(position=(-2.0, 2.0, 16.0), color=(0.5, 0.5, 0.5)),
+                Light(position=(2.0, 2.0, 16.0), color=(0.5, 0.5, 0.5), area_a=(0.0, 0.5, 0.0), area_b=(0.5, 0.0, 0.0))],
+        ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.0, 5.04746, 24.827951), center=(0.012231, -0.459716, -15.800501), fovy_degrees=25.0)
+    return scene, cam, (910, 512)
+
+
+# more reference scene scripts (not in BASELINE.json's configs): pins for smooth shading, glossy reflection, area lights
+MORE_EXAMPLES = {"smooth-shading": smooth_shading, "glossy-reflection": glossy_reflection, "soft-shadows": soft_shadows}
 
 
 EXAMPLES = {

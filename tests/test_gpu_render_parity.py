@@ -69,6 +69,24 @@ def test_example_matches_oracle(oracle, host, H, name, size, mode):
     r.close()
 
 
+@pytest.mark.parametrize("name", ["smooth-shading", "glossy-reflection", "soft-shadows"])
+@pytest.mark.parametrize("mode", ["flat", "kd"])
+def test_more_reference_scenes_match_oracle(oracle, host, H, name, mode):
+    """Vertex-normal interpolation, glossy reflection offsets and area-light samples (the last two draw
+    from the counter-based generator inside hit_color: same draw indices on both sides)."""
+    from example_scenes import MORE_EXAMPLES
+    scene, cam, _ = MORE_EXAMPLES[name]()
+    w, h = 364, 204
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_KD if mode == "kd" else H.TRAVERSE_FLAT)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=3, seed=11, sample_mode=H.SAMPLE_RNG, stats=True)
+    ref = oracle.render(scene, cam, w, h, samples=3, seed=11, jitter=oracle.JITTER_RNG, mode=oracle.MODE_KD if mode == "kd" else oracle.MODE_FLAT)
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert np.array_equal(rgb, ref.rgb)
+    assert ulp_diff(linear, ref.linear).max() <= 256
+    r.close()
+
+
 @pytest.mark.parametrize("samples", [8, 20, 64])
 def test_samples_and_jitter_match_oracle(oracle, host, H, samples):
     """SAMPLES > 1 with the counter-based jitter: same sample positions, same summation order (chunks of
