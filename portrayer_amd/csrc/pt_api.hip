@@ -224,7 +224,7 @@ struct pt_context {
     std::string err;
     PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh_items, kd, kd_items;
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, mkd, mkd_items;
-    PtBuf node_box, kd_box;
+    PtBuf node_box, kd_box, mkd_box, mkd_item_box;
     PtBuf frames, accum, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
     PtSceneView view;
     bool have_scene = false;
@@ -290,7 +290,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box};
+                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -431,6 +431,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     // ---- KDMesh triangle trees (reference structure)
     std::vector<PtKdNode> mkd;
     std::vector<uint32_t> mkd_items;
+    std::vector<float> mkd_box, mkd_item_box;  // conservative f32 bounds per KDMesh tree node / per leaf reference (pt_kdmesh_hit's culls)
     int max_kdm_depth = 0;
     bool any_kdmesh = false;
     if (s->mesh_kd_root && s->n_kdm_nodes) {
@@ -450,23 +451,43 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
             }
         }
         mkd_items.assign(s->n_kdm_items, 0);
+        mkd_box.assign(6 * (size_t)s->n_kdm_nodes, 0.0f);
+        mkd_item_box.assign(6 * (size_t)s->n_kdm_items, 0.0f);
         // leaf items are local triangle indices: make them global, mesh by mesh (a leaf belongs to the mesh whose tree reaches it)
         std::vector<int32_t> owner(s->n_kdm_nodes, -1);
         for (uint32_t m = 0; m < s->n_meshes; m++) {
             int32_t root = s->mesh_kd_root[m];
             if (root < 0) continue;
             if ((uint32_t)root >= s->n_kdm_nodes) return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh root out of range");
-            std::vector<int32_t> todo{root};
+            std::vector<int32_t> todo{root}, visited;
+            const double tri_pad = 1e-7 * std::max(std::max(mesh_box[m].hi[0] - mesh_box[m].lo[0], mesh_box[m].hi[1] - mesh_box[m].lo[1]),
+                                                   std::max(mesh_box[m].hi[2] - mesh_box[m].lo[2], 1e-30));
             while (!todo.empty()) {
                 int32_t i = todo.back(); todo.pop_back();
                 if (owner[i] >= 0) return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh trees must not share nodes");
                 owner[i] = (int32_t)m;
+                visited.push_back(i);
                 if (mkd[i].axis >= 0) { todo.push_back(mkd[i].front); todo.push_back(mkd[i].back); }
                 else for (int32_t k = 0; k < mkd[i].count; k++) {
                     int32_t local = s->kdm_items[mkd[i].first + k];
                     if (local < 0 || (uint64_t)local >= s->mesh_tri_off[m + 1] - s->mesh_tri_off[m]) return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh leaf triangle out of range");
-                    mkd_items[mkd[i].first + k] = (uint32_t)(s->mesh_tri_off[m] + (uint64_t)local);
+                    const uint64_t g = s->mesh_tri_off[m] + (uint64_t)local;
+                    mkd_items[mkd[i].first + k] = (uint32_t)g;
+                    float* ib = &mkd_item_box[6 * (size_t)(mkd[i].first + k)];  // the triangle's padded box, for the walk's pre-cull
+                    for (int r = 0; r < 3; r++) {
+                        const double* v = &tri_v[9 * g];
+                        ib[r] = pt_bvh_detail::round_down(std::min(v[r], std::min(v[3 + r], v[6 + r])) - tri_pad);
+                        ib[3 + r] = pt_bvh_detail::round_up(std::max(v[r], std::max(v[3 + r], v[6 + r])) + tri_pad);
+                    }
                 }
+            }
+            for (size_t vi = visited.size(); vi-- > 0;) {  // children were discovered after their parents: bounds bottom-up
+                const int32_t i = visited[vi];
+                float* b = &mkd_box[6 * (size_t)i];
+                for (int r = 0; r < 3; r++) { b[r] = (float)PT_BOX_LIMIT; b[3 + r] = -(float)PT_BOX_LIMIT; }
+                auto grow = [&](const float* o) { for (int r = 0; r < 3; r++) { b[r] = std::min(b[r], o[r]); b[3 + r] = std::max(b[3 + r], o[3 + r]); } };
+                if (mkd[i].axis >= 0) { grow(&mkd_box[6 * (size_t)mkd[i].front]); grow(&mkd_box[6 * (size_t)mkd[i].back]); }
+                else for (int32_t k = 0; k < mkd[i].count; k++) grow(&mkd_item_box[6 * (size_t)(mkd[i].first + k)]);
             }
             PtMeshInfo& mi = meshes[m];
             mi.kd_root = root;
@@ -633,7 +654,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
         (rc = pt_upload(c, c->meshes, meshes)) || (rc = pt_upload(c, c->node_box, node_box32)) || (rc = pt_upload(c, c->kd_box, kd_box32)) ||
         (rc = pt_upload(c, c->kd, kdn)) || (rc = pt_upload(c, c->kd_items, kdi)) || (rc = pt_upload(c, c->mkd, mkd)) ||
-        (rc = pt_upload(c, c->mkd_items, mkd_items)))
+        (rc = pt_upload(c, c->mkd_items, mkd_items)) || (rc = pt_upload(c, c->mkd_box, mkd_box)) || (rc = pt_upload(c, c->mkd_item_box, mkd_item_box)))
         return rc;
     std::vector<double> mats(s->materials, s->materials + 10 * (size_t)s->n_materials);
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
@@ -715,6 +736,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.kd_box = traverse == PT_TRAVERSE_KD ? (const float*)c->kd_box.p : nullptr;
     if (getenv("PORTRAYER_KD_NO_CULL")) v.kd_box = v.node_box = nullptr;  // experiment: the reference's walk as it is
     v.mkd = (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;
+    v.mkd_box = mkd_box.empty() || getenv("PORTRAYER_KD_NO_CULL") ? nullptr : (const float*)c->mkd_box.p;
+    v.mkd_item_box = v.mkd_box ? (const float*)c->mkd_item_box.p : nullptr;
     v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
     // mesh-heavy scenes spend > 90 % of the wave cycles in the tree walk and gain from a 4th wave (big-soup 2.46 -> 2.75 Gray/s);
     // scenes with a few small meshes lose (mirror 11.8 -> 10.7, cows 8.9 -> 7.8)

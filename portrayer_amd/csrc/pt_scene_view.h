@@ -89,6 +89,8 @@ struct PtSceneView {
     // KDMesh triangle trees, the reference's structure (kdtree/kdmesh.rs); items are global triangle indices
     const PtKdNode* mkd;
     const uint32_t* mkd_items;
+    const float* mkd_box;       // per mkd node: union of the padded triangle boxes below it (6 f32, outward); null = no culling
+    const float* mkd_item_box;  // per mkd_items entry: that triangle's padded box
 };
 
 struct PtCamera {  // camera.rs:17-31, built on the host (look_at inverse, tan)

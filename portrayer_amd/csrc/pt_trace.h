@@ -186,14 +186,24 @@ PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay
     int32_t cur = m.kd_root;
     const double extent = m.kd_extent;
     const double end0 = end;  // a pending far side's range end = the start of the entry below it, or end0
+    const PtRay32 q = pt_ray32(local);
     for (;;) {
         const PtKdNode n = sc.mkd[cur];
-        if (n.axis < 0) {  // leaf: [T]::ray_hit (ray.rs:50-63) over the leaf's triangles, in order, strict shrinking end
+        // conservative culls as in pt_trace_kd: a subtree / a triangle whose box the segment [start, end) does not reach reports no hit
+        float seg0 = (float)start, seg1 = (float)end;
+        seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
+        if (sc.mkd_box && !pt_slab32_segment(sc.mkd_box + 6 * (size_t)cur, sc.mkd_box + 6 * (size_t)cur + 3, q, seg0, seg1)) {
+            if (STATS) cnt->kd_culled++;
+        } else if (n.axis < 0) {  // leaf: [T]::ray_hit (ray.rs:50-63) over the leaf's triangles, in order, strict shrinking end
             if (STATS) cnt->n_leaf++;
             bool found = false;
             double e = end;
             for (int32_t i = 0; i < n.count; i++) {
                 uint32_t tri = sc.mkd_items[n.first + i];
+                if (sc.mkd_item_box) {
+                    const float* ib = sc.mkd_item_box + 6 * (size_t)(n.first + i);
+                    if (!pt_slab32_segment(ib, ib + 3, q, seg0, seg1)) continue;
+                }
                 double tt, beta, gamma;
                 if (STATS) cnt->n_tri++;
                 if (pt_triangle_hit(sc.tri_v + 9 * (size_t)tri, local, start, e, &tt, &beta, &gamma)) { e = tt; *t_out = tt; *tri_out = tri; found = true; }
