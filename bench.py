@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="testing: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare rank 0's assembled image with a single-GPU render")
+    ap.add_argument("--no-pipeline", action="store_true", help="nccl path: wait for each frame's gather before rendering the next")
     ap.add_argument("--force-dist", action="store_true", help="testing: take the torch.distributed path even with one rank")
     ap.add_argument("--share", type=int, default=1, help="testing: render only one rank's tiles of an N-rank partition (no gather)")
     ap.add_argument("--share-rank", type=int, default=0, help="testing: which rank's tiles --share renders")
@@ -161,9 +162,11 @@ def main():
         dev = torch.device("cpu") if args.backend == "gloo" else torch.device(f"cuda:{device}")
         if args.backend == "nccl":
             torch.cuda.set_device(device)
-        mine_t = torch.empty(compact_bytes, dtype=torch.uint8, device=dev)
-        gathered_t = torch.empty(compact_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None
-        gather_list = list(gathered_t.chunk(world)) if rank == 0 else None  # views: the gather lands rank-major in one buffer
+        # two sets of buffers: frame k+1 is rendered while frame k's tiles travel (nccl path)
+        mine_ts = [torch.empty(compact_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        gathered_ts = [torch.empty(compact_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
+        gather_lists = [list(g.chunk(world)) if rank == 0 else None for g in gathered_ts]  # views: the gather lands rank-major in one buffer
+        mine_t, gathered_t, gather_list = mine_ts[0], gathered_ts[0], gather_lists[0]
     d_mine = C.c_void_p()
     if use_dist and args.backend == "gloo":
         check(lib.pt_device_alloc(ctx, compact_bytes, C.byref(d_mine)), "pt_device_alloc")
@@ -206,6 +209,33 @@ def main():
                 check(lib.pt_synchronize(ctx), "pt_synchronize")
         return st.as_dict()
 
+    # Pipelined frames (nccl): the render of frame k runs while frame k-1's gather is in flight and is
+    # followed in the stream by frame k-1's untile; nothing waits for a collective except the drain.
+    pending = []  # (async gather handle, buffer index, params) of the frame whose tiles are still travelling
+
+    def finish_pending():
+        if not pending:
+            return
+        work, b, pp = pending.pop()
+        work.wait()  # the current torch stream waits for the gather ...
+        torch.cuda.current_stream().synchronize()  # ... and the host for that stream only (not for our render stream): the send buffer is free again
+        if rank == 0:
+            check(lib.pt_untile_device(ctx, C.byref(pp), C.c_void_p(gathered_ts[b].data_ptr()), d_full, None), "pt_untile_device")
+
+    def step_pipelined(k):
+        b = k & 1
+        pp = params(False)
+        st = H.PtStats()
+        check(lib.pt_render_device(ctx, C.byref(cam), d_bg, C.byref(pp), 1, C.c_void_p(mine_ts[b].data_ptr()), None), "pt_render_device")
+        finish_pending()  # frame k-1: its untile queues behind frame k's render
+        check(lib.pt_render_finish(ctx, C.byref(st)), "pt_render_finish")
+        pending.append((dist.gather(mine_ts[b], gather_lists[b], dst=0, async_op=True), b, pp))
+        return st.as_dict()
+
+    def drain():
+        finish_pending()
+        check(lib.pt_synchronize(ctx), "pt_synchronize")
+
     # counting pass (untimed): ray / node / test counters of this rank's share of one frame
     counts = step(stats=True)
     if counts["stack_overflow"]:
@@ -221,13 +251,16 @@ def main():
     if os.environ.get("PT_DUMP_COUNTERS") and rank == 0:  # kernel experiments (profiles/ab.sh builds with -DPT_PHASE_TIMING)
         print("counters", json.dumps({k: int(v) if isinstance(v, (int, np.integer)) else v for k, v in counts.items()}), file=sys.stderr)
 
+    pipelined = use_dist and args.backend == "nccl" and not args.no_pipeline
     for _ in range(args.warmup):
         step()
     sync_all()
     t0 = time.perf_counter()
     kernel_ms = []
-    for _ in range(args.steps):
-        kernel_ms.append(step()["kernel_ms"])
+    for k in range(args.steps):
+        kernel_ms.append((step_pipelined(k) if pipelined else step())["kernel_ms"])
+    if pipelined:
+        drain()  # every frame assembled on rank 0 before the clock stops
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
