@@ -25,6 +25,9 @@ Example primitives_simple();                                     // examples/pri
 Example macho_cows(const std::string& assets_dir);               // examples/macho-cows.rs
 Example entering_the_mirror_dimension(const std::string& assets_dir);  // examples/entering-the-mirror-dimension.rs
 Example big_scene(int n = 10);                                   // examples/big-scene.rs (n = objects per axis)
+Example smooth_shading(const std::string& assets_dir);           // examples/smooth-shading.rs
+Example glossy_reflection();                                     // examples/glossy-reflection.rs
+Example soft_shadows(const std::string& assets_dir);             // examples/soft-shadows.rs
 
 int run_main(Example ex);  // Image::new(..)? ; image.render::<RenderProgress, _>(..) ; image.save()
 

@@ -160,6 +160,9 @@ static examples::Example make_example(const std::string& name, const std::string
     if (name == "macho-cows") return examples::macho_cows(assets);
     if (name == "entering-the-mirror-dimension") return examples::entering_the_mirror_dimension(assets);
     if (name == "big-scene") return examples::big_scene(n > 1 ? n : 10);
+    if (name == "smooth-shading") return examples::smooth_shading(assets);
+    if (name == "glossy-reflection") return examples::glossy_reflection();
+    if (name == "soft-shadows") return examples::soft_shadows(assets);
     throw std::runtime_error("unknown example scene: " + name);
 }
 

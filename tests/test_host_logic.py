@@ -10,7 +10,9 @@ import pytest
 
 import device_glue
 import host_glue
-from example_scenes import EXAMPLES, big_scene
+from example_scenes import EXAMPLES as _BASELINE_EXAMPLES, MORE_EXAMPLES, big_scene
+
+EXAMPLES = {**_BASELINE_EXAMPLES, **MORE_EXAMPLES}
 from scene_dsl import ASSETS, MeshData
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
