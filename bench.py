@@ -281,15 +281,16 @@ def main():
         mine_bytes = algorithmic_bytes(counts, n_lights, compact_bytes // 3 if use_dist else w * h, args.traversal)
         achieved = mine_bytes / mean_kernel_s / 1e9
         out = {
-            "metric": "Mray/s (primary+shadow+secondary) at 1920x1080 SAMPLES=64",
+            "metric": "Mray/s (primary+shadow+secondary) at 1920x1080 SAMPLES=64" if (w, h, s) == (1920, 1080, 64) else f"Mray/s (primary+shadow+secondary) at {w}x{h} SAMPLES={s}",
             "value": rays_frame * args.steps / elapsed / 1e6,
             "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{example} ({'1000 analytic primitives, 3 point lights, ' if example == 'big-scene' else ''}"
-                                   f"reference scene script) {w}x{h} SAMPLES={s}",
+            "config": {"workload": (f"{example} (the big-scene generator over cow.obj: 216 instances, 1,253,664 triangles; SURVEY 8d synthetic) {w}x{h} SAMPLES={s}"
+                                    if example.startswith("synthetic:") else
+                                    f"{example} ({'1000 analytic primitives, 3 point lights, ' if example == 'big-scene' else ''}reference scene script) {w}x{h} SAMPLES={s}"),
                        "width": w, "height": h, "samples": s, "traversal": args.traversal, "sampling": "counter-based jitter, seed 0",
                        "partition": f"8x8 tiles round-robin over {world} rank(s), one gather" if world > 1 else "single GPU",
                        "rays_per_frame": rays_frame,

@@ -7,11 +7,11 @@ OUT=$ROOTDIR/gpurun_out/pmcq_$$
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --pmc $CTRS --output-format csv -d $OUT -- python3 $ROOTDIR/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/log.txt 2>&1
 python3 - <<PY
-import csv,glob,collections
+import csv,glob,collections,re
 f=glob.glob('$OUT/*/*_counter_collection.csv')
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open(f[0])):
-    if 'pt_render_kernel<' in r['Kernel_Name'] and ', false, ' in r['Kernel_Name']:
+    if re.search(r'pt_render_kernel<\d+, false,', r['Kernel_Name']):
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in sorted(agg.items()): print('%-28s %.4g' % (k, sum(v)/len(v)))
 PY

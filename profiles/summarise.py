@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns a gpurun_out/prof_<tag> directory (written by profiles/run_profile.sh) into the committed
 summary files: profiles/<round>/<tag>_kernel_stats.csv, <tag>_pmc.json and profiles/traffic.json."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 tag, rnd = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "big-scene/flat/gpus1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,12 +14,12 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
     for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "pt_render_kernel<" in r["Kernel_Name"] and ", false, " in r["Kernel_Name"]:
+            if re.search(r"pt_render_kernel<\d+, false,", r["Kernel_Name"]):  # the timed kernel (STATS = false), not the counting launch
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
 for line in open(f"{dst}/{tag}_kernel_stats.csv"):
-    if "pt_render_kernel<" in line and ", false, " in line:  # the timed kernel (STATS = false), not the counting launch
+    if re.search(r"pt_render_kernel<\d+, false,", line):
         out["kernel_trace_avg_ns"] = float(line.split('","')[-5] if False else line.strip().split(",")[-5].strip('"'))
 json.dump(out, open(f"{dst}/{tag}_pmc.json", "w"), indent=1)
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
