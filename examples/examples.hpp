@@ -28,6 +28,9 @@ Example big_scene(int n = 10);                                   // examples/big
 Example smooth_shading(const std::string& assets_dir);           // examples/smooth-shading.rs
 Example glossy_reflection();                                     // examples/glossy-reflection.rs
 Example soft_shadows(const std::string& assets_dir);             // examples/soft-shadows.rs
+Example hier(const std::string& assets_dir);                     // examples/hier.rs
+Example instance(const std::string& assets_dir);                 // examples/instance.rs
+Example antialiasing(const std::string& assets_dir);             // examples/antialiasing.rs (its main() renders twice)
 
 int run_main(Example ex);  // Image::new(..)? ; image.render::<RenderProgress, _>(..) ; image.save()
 

@@ -163,6 +163,9 @@ static examples::Example make_example(const std::string& name, const std::string
     if (name == "smooth-shading") return examples::smooth_shading(assets);
     if (name == "glossy-reflection") return examples::glossy_reflection();
     if (name == "soft-shadows") return examples::soft_shadows(assets);
+    if (name == "hier") return examples::hier(assets);
+    if (name == "instance") return examples::instance(assets);
+    if (name == "antialiasing") return examples::antialiasing(assets);
     throw std::runtime_error("unknown example scene: " + name);
 }
 

@@ -4,7 +4,7 @@ Scene constants are taken from the reference's scene scripts (data, not code):
   examples/single-triangle.rs:17-58, examples/primitives-simple.rs:17-76,
   examples/macho-cows.rs:17-128, examples/entering-the-mirror-dimension.rs:17-188,
   examples/big-scene.rs:26-109, examples/smooth-shading.rs:17-100, examples/glossy-reflection.rs:17-87,
-  examples/soft-shadows.rs:17-95.
+  examples/soft-shadows.rs:17-95, examples/hier.rs:17-101, examples/instance.rs:17-95, examples/antialiasing.rs:18-50.
 The product has its own C++ transliteration of the same scripts (examples/*.cpp); the tests check
 that both produce identical node matrices.
 """
@@ -204,8 +204,52 @@ def soft_shadows():
     return scene, cam, (910, 512)
 
 
+def _arch(mat):
+    return [Node.geo(Cube(), mat).scaled((0.8, 4.0, 0.8)).translated((-2.0, 2.0, 0.0)),
+            Node.geo(Cube(), mat).scaled((0.8, 4.0, 0.8)).translated((2.0, 2.0, 0.0)),
+            Node.geo(Sphere(), mat).scaled((4.0, 0.6, 0.6)).translated((0.0, 4.0, 0.0))]
+
+
+def hier():
+    gold = Material(diffuse=(0.9, 0.8, 0.4), specular=(0.8, 0.8, 0.4), shininess=25.0)
+    grass = Material(diffuse=(0.1, 0.7, 0.1))
+    blue = Material(diffuse=(0.7, 0.6, 1.0), specular=(0.5, 0.4, 0.8), shininess=25.0)
+    arc = Node.group(_arch(gold)).translated((0.0, 0.0, -10.0)).rotated_y(to_radians(60.0))
+    floor = Node.geo(Mesh(load_mesh("plane.obj")), grass).scaled(30.0)
+    poly = Node.geo(Mesh(load_mesh("dodeca.obj")), blue).translated((-2.0, 1.618034, 0.0))
+    scene = Scene(root=Node.group([arc, floor, poly]).rotated_x(to_radians(23.0)).translated((6.0, -2.0, -15.0)),
+                  lights=[Light(position=(200.0, 200.0, 400.0), color=(0.8, 0.8, 0.8)), Light(position=(0.0, 5.0, -20.0), color=(0.4, 0.4, 0.8))],
+                  ambient=(0.4, 0.4, 0.4))
+    cam = Camera(eye=(0.0, 0.0, 0.0), center=(0.0, 0.0, -1.0), fovy_degrees=50.0)
+    return scene, cam, (256, 256)
+
+
+def instance():
+    stone = Material(diffuse=(0.8, 0.7, 0.7))
+    grass = Material(diffuse=(0.1, 0.7, 0.1))
+    arc = Node.group(_arch(stone)).translated((0.0, 0.0, -10.0))
+    nodes = [Node.group([arc]).rotated_y(to_radians(60.0 * float(i))) for i in range(1, 7)]
+    nodes.append(Node.geo(Mesh(load_mesh("plane.obj")), grass).scaled(30.0))
+    nodes.append(Node.geo(Sphere(), stone).scaled(2.5))
+    scene = Scene(root=Node.group(nodes).rotated_x(to_radians(23.0)),
+                  lights=[Light(position=(200.0, 202.0, 430.0), color=(0.8, 0.8, 0.8))],
+                  ambient=(0.4, 0.4, 0.4))
+    cam = Camera(eye=(0.0, 2.0, 30.0), center=(0.0, 2.0, 29.0), fovy_degrees=50.0)
+    return scene, cam, (256, 256)
+
+
+def antialiasing():
+    mat_monkey = Material(diffuse=(0.961, 0.573, 0.259), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    scene = Scene(root=Node.group([Node.geo(Mesh(load_mesh("monkey.obj")), mat_monkey)]),
+                  lights=[Light(position=(0.0, 0.0, 10.0), color=(0.5, 0.5, 0.5))],
+                  ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.0, 0.0, 6.5), center=(0.0, 0.0, 0.0), fovy_degrees=20.0)
+    return scene, cam, (300, 250)
+
+
 # more reference scene scripts (not in BASELINE.json's configs): pins for smooth shading, glossy reflection, area lights
-MORE_EXAMPLES = {"smooth-shading": smooth_shading, "glossy-reflection": glossy_reflection, "soft-shadows": soft_shadows}
+MORE_EXAMPLES = {"smooth-shading": smooth_shading, "glossy-reflection": glossy_reflection, "soft-shadows": soft_shadows,
+                 "hier": hier, "instance": instance, "antialiasing": antialiasing}
 
 
 EXAMPLES = {

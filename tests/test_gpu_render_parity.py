@@ -69,7 +69,7 @@ def test_example_matches_oracle(oracle, host, H, name, size, mode):
     r.close()
 
 
-@pytest.mark.parametrize("name", ["smooth-shading", "glossy-reflection", "soft-shadows"])
+@pytest.mark.parametrize("name", ["smooth-shading", "glossy-reflection", "soft-shadows", "hier", "instance", "antialiasing"])
 @pytest.mark.parametrize("mode", ["flat", "kd"])
 def test_more_reference_scenes_match_oracle(oracle, host, H, name, mode):
     """Vertex-normal interpolation, glossy reflection offsets and area-light samples (the last two draw
