@@ -30,6 +30,7 @@ Example glossy_reflection();                                     // examples/glo
 Example soft_shadows(const std::string& assets_dir);             // examples/soft-shadows.rs
 Example hier(const std::string& assets_dir);                     // examples/hier.rs
 Example instance(const std::string& assets_dir);                 // examples/instance.rs
+Example fish(const std::string& assets_dir);                     // examples/fish.rs (PNG texture on a mesh with `vt` records)
 Example antialiasing(const std::string& assets_dir);             // examples/antialiasing.rs (its main() renders twice)
 
 int run_main(Example ex);  // Image::new(..)? ; image.render::<RenderProgress, _>(..) ; image.save()

@@ -166,6 +166,7 @@ static examples::Example make_example(const std::string& name, const std::string
     if (name == "hier") return examples::hier(assets);
     if (name == "instance") return examples::instance(assets);
     if (name == "antialiasing") return examples::antialiasing(assets);
+    if (name == "fish") return examples::fish(assets);
     throw std::runtime_error("unknown example scene: " + name);
 }
 

@@ -4,7 +4,7 @@ Scene constants are taken from the reference's scene scripts (data, not code):
   examples/single-triangle.rs:17-58, examples/primitives-simple.rs:17-76,
   examples/macho-cows.rs:17-128, examples/entering-the-mirror-dimension.rs:17-188,
   examples/big-scene.rs:26-109, examples/smooth-shading.rs:17-100, examples/glossy-reflection.rs:17-87,
-  examples/soft-shadows.rs:17-95, examples/hier.rs:17-101, examples/instance.rs:17-95, examples/antialiasing.rs:18-50.
+  examples/soft-shadows.rs:17-95, examples/hier.rs:17-101, examples/instance.rs:17-95, examples/antialiasing.rs:18-50, examples/fish.rs:17-63.
 The product has its own C++ transliteration of the same scripts (examples/*.cpp); the tests check
 that both produce identical node matrices.
 """
@@ -295,7 +295,19 @@ def normal_mapping(light_pos=(0.0, 8.0, 10.0)):
     return scene, cam, (910, 512)
 
 
-TEXTURED_EXAMPLES = {"normal-mapping": normal_mapping}
+def fish():
+    from scene_dsl import Texture
+    mat_fish = Material(diffuse=(0.8, 0.8, 0.8), specular=(0.3, 0.3, 0.3), shininess=25.0, texture=Texture.open(os.path.join(ASSETS, "fish.png")))
+    model = load_mesh("fish.obj")
+    scene = Scene(root=Node.group([Node.geo(Mesh(model, smooth=True), mat_fish).rotated_y(to_radians(30.0)),
+                                   Node.geo(Mesh(model, smooth=True), mat_fish).rotated_y(to_radians(210.0))]),
+                  lights=[Light(position=(0.0, 0.0, 10.0), color=(0.9, 0.9, 0.9))],
+                  ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.0, 0.0, 11.0), center=(0.0, 0.0, 0.0), fovy_degrees=25.0)
+    return scene, cam, (910, 512)
+
+
+TEXTURED_EXAMPLES = {"normal-mapping": normal_mapping, "fish": fish}
 
 
 def big_mesh(n: int = 6):
