@@ -96,6 +96,9 @@ int ph_renderer_render(ph_renderer *r, const double camera[10], const pt_render_
 int ph_example_render_to_png(const char *name, const char *assets_dir, int n, uint32_t width, uint32_t height, const char *png_path);
 int ph_png_read(const char *path, uint32_t size[2], uint8_t *rgb, uint64_t cap);
 int ph_png_write(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);
+/* Texture files as texture::RgbImageBuffer::open reads them (src/texture.rs:104-141 via the `image` crate): PNG or
+ * JPEG (baseline and progressive), decoded to RGB8. size = {width, height}; rgb may be NULL to query the size. */
+int ph_image_read(const char *path, uint32_t size[2], uint8_t *rgb, uint64_t cap);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ _dp, _ip, _up, _u64p, _u8p = H._dp, H._ip, H._up, H._u64p, H._u8p
 
 EXPORTS = ["ph_last_error", "ph_scene_create", "ph_example_scene", "ph_scene_destroy", "ph_scene_counts", "ph_scene_export",
            "ph_scene_flatten", "ph_scene_kdtree", "ph_camera", "ph_obj_load", "ph_renderer_create", "ph_renderer_destroy",
-           "ph_renderer_context", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write"]
+           "ph_renderer_context", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write", "ph_image_read"]
 
 
 class PortrayerHostError(RuntimeError):
@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
         l.ph_example_render_to_png.restype = C.c_int
         l.ph_example_render_to_png.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_char_p]
         l.ph_png_read.restype = C.c_int; l.ph_png_read.argtypes = [C.c_char_p, _up, _u8p, C.c_uint64]
+        l.ph_image_read.restype = C.c_int; l.ph_image_read.argtypes = [C.c_char_p, _up, _u8p, C.c_uint64]
         l.ph_png_write.restype = C.c_int; l.ph_png_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _u8p]
         _lib = l
     return _lib

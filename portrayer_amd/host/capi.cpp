@@ -442,6 +442,21 @@ extern "C" int ph_png_read(const char* path, uint32_t size[2], uint8_t* rgb, uin
         return PH_OK;
     });
 }
+extern "C" int ph_image_read(const char* path, uint32_t size[2], uint8_t* rgb, uint64_t cap) {
+    if (!path || !size) return bad("null argument");
+    return guarded([&]() -> int {
+        size_t w = 0, h = 0;
+        std::vector<uint8_t> buf;
+        if (!detail::image_read(path, &w, &h, &buf)) { g_error = "file not found"; return PH_ERR_RUNTIME; }
+        size[0] = (uint32_t)w; size[1] = (uint32_t)h;
+        if (rgb) {
+            if (cap < buf.size()) return bad("buffer too small");
+            std::memcpy(rgb, buf.data(), buf.size());
+        }
+        return PH_OK;
+    });
+}
+
 extern "C" int ph_png_write(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb) {
     if (!path || !rgb) return bad("null argument");
     return guarded([&]() -> int {

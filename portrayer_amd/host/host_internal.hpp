@@ -84,6 +84,8 @@ class Renderer {
 
 // PNG codec for Image::new / Image::save (render.rs:165-208; the reference uses the `image` crate)
 bool png_read(const std::string& path, size_t* width, size_t* height, std::vector<uint8_t>* rgb);
+bool jpeg_read(const std::string& path, size_t* width, size_t* height, std::vector<uint8_t>* rgb);   // jpeg.cpp
+bool image_read(const std::string& path, size_t* width, size_t* height, std::vector<uint8_t>* rgb);  // PNG or JPEG, by signature
 void png_write(const std::string& path, size_t width, size_t height, const std::vector<uint8_t>& rgb);
 
 }  // namespace detail

@@ -211,7 +211,7 @@ KDMesh::KDMesh(const Arc<MeshData>& d, Shading s) : data(d), shading(s) {
 namespace texture {
 RgbImageBuffer RgbImageBuffer::open(const std::string& path) {
     RgbImageBuffer b;
-    if (!detail::png_read(path, &b.width, &b.height, &b.rgb)) throw std::runtime_error("could not open texture image: " + path);
+    if (!detail::image_read(path, &b.width, &b.height, &b.rgb)) throw std::runtime_error("could not open texture image: " + path);
     return b;
 }
 RgbImageBuffer RgbImageBuffer::from_pixels(size_t width, size_t height, const uint8_t* rgb) {
@@ -656,6 +656,16 @@ void Renderer::render(const camera::CameraSettings& cam, uint32_t width, uint32_
 // PNG (8-bit RGB / RGBA / grey, non-interlaced)
 // ------------------------------------------------------------------------------------------------
 static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+bool image_read(const std::string& path, size_t* width, size_t* height, std::vector<uint8_t>* rgb) {
+    unsigned char sig[2] = {0, 0};
+    {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) return false;
+        in.read(reinterpret_cast<char*>(sig), 2);
+    }
+    return (sig[0] == 0xFF && sig[1] == 0xD8) ? jpeg_read(path, width, height, rgb) : png_read(path, width, height, rgb);
+}
 
 bool png_read(const std::string& path, size_t* width, size_t* height, std::vector<uint8_t>* rgb) {
     std::ifstream in(path, std::ios::binary);

@@ -141,7 +141,7 @@ namespace texture {  // src/texture.rs
 struct RgbImageBuffer {  // texture.rs:74-141: the decoded RGB8 pixels, no colour correction
     size_t width = 0, height = 0;
     std::vector<uint8_t> rgb;
-    static RgbImageBuffer open(const std::string& path);  // PNG (the reference's `image` crate also reads JPEG)
+    static RgbImageBuffer open(const std::string& path);  // PNG or JPEG, told apart by the file's first bytes
     static RgbImageBuffer from_pixels(size_t width, size_t height, const uint8_t* rgb);
 };
 struct ImageTexture {  // texture.rs:143-169: sampled colours go sRGB -> linear with powf(2.2)

@@ -168,6 +168,46 @@ def test_png_codec_roundtrip(tmp_path):
     assert np.array_equal(out, g)
 
 
+def _image_read(path):
+    from portrayer_amd import host
+    size = np.zeros(2, dtype=np.uint32)
+    assert host.lib().ph_image_read(path.encode(), size.ctypes.data_as(host._up), None, 0) == 0
+    out = np.zeros((int(size[1]), int(size[0]), 3), dtype=np.uint8)
+    assert host.lib().ph_image_read(path.encode(), size.ctypes.data_as(host._up), out.ctypes.data_as(host._u8p), out.size) == 0
+    return out
+
+
+@pytest.mark.parametrize("name", ["Brick_Wall_013_COLOR.jpg",             # baseline, 4:2:0, 1025 x 1025 (odd: partial MCUs, replicated chroma edges)
+                                  "Rock_033_baseColor_2.jpg",             # baseline, 4:4:4
+                                  "Terracotta_Tiles_002_Base_Color.jpg",  # progressive, 4:2:0
+                                  "Terracotta_Tiles_002_Normal.jpg",      # progressive, 4:2:0
+                                  "Stone_Wall_007_NORM_cubemap.jpg"])     # baseline, 4:4:4, 4096 x 3072
+def test_jpeg_decoder_equals_libjpeg(name):
+    """The C++ host's JPEG reader (portrayer_amd/host/jpeg.cpp) follows libjpeg's default decompression path
+    (islow IDCT, fancy upsampling, fixed-point YCbCr tables): the texels it hands to the device are the ones
+    Pillow hands to the oracle in the textured parity tests, bit for bit."""
+    from PIL import Image
+    path = os.path.join(ROOT, "tests", "golden", "assets", name)
+    assert np.array_equal(_image_read(path), np.array(Image.open(path).convert("RGB")))
+
+
+def test_jpeg_decoder_synthetic_variants(tmp_path):
+    """Grey, 4:2:2, restart intervals, tiny and odd sizes, progressive with many scans - written by Pillow."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    base = np.clip(rng.normal(128, 50, (67, 45, 3)).cumsum(axis=1) / 6 % 256, 0, 255).astype(np.uint8)
+    cases = [dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, progressive=True), dict(subsampling=1, progressive=True),
+             dict(subsampling=2, restart_marker_blocks=3), dict(subsampling=0, quality=30, optimize=True), dict(subsampling=2, quality=98, progressive=True, restart_marker_rows=1)]
+    for i, kw in enumerate(cases):
+        for img in (base, base[:9, :3], base[:16, :16], base[:1, :1]):
+            p = str(tmp_path / f"v{i}.jpg")
+            Image.fromarray(img).save(p, **{"quality": 85, **kw})
+            assert np.array_equal(_image_read(p), np.array(Image.open(p).convert("RGB"))), (kw, img.shape)
+        p = str(tmp_path / f"g{i}.jpg")
+        Image.fromarray(base[:, :, 0]).save(p, quality=80, progressive=bool(kw.get("progressive")))
+        assert np.array_equal(_image_read(p), np.array(Image.open(p).convert("RGB")))
+
+
 def test_no_gpu_means_loud_failure():
     """Without an MI355X the product must raise, never fall back to a CPU path."""
     from portrayer_amd import _hip, host
