@@ -31,6 +31,7 @@ Example soft_shadows(const std::string& assets_dir);             // examples/sof
 Example hier(const std::string& assets_dir);                     // examples/hier.rs
 Example instance(const std::string& assets_dir);                 // examples/instance.rs
 Example fish(const std::string& assets_dir);                     // examples/fish.rs (PNG texture on a mesh with `vt` records)
+Example normal_mapping(const std::string& assets_dir, math::Vec3 light_pos = math::Vec3{0.0, 8.0, 10.0});  // examples/normal-mapping.rs (JPEG textures + normal maps; its main() renders three light positions)
 Example antialiasing(const std::string& assets_dir);             // examples/antialiasing.rs (its main() renders twice)
 
 int run_main(Example ex);  // Image::new(..)? ; image.render::<RenderProgress, _>(..) ; image.save()

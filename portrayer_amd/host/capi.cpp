@@ -167,6 +167,7 @@ static examples::Example make_example(const std::string& name, const std::string
     if (name == "instance") return examples::instance(assets);
     if (name == "antialiasing") return examples::antialiasing(assets);
     if (name == "fish") return examples::fish(assets);
+    if (name == "normal-mapping") return examples::normal_mapping(assets);
     throw std::runtime_error("unknown example scene: " + name);
 }
 
