@@ -4,7 +4,7 @@ Scene constants are taken from the reference's scene scripts (data, not code):
   examples/single-triangle.rs:17-58, examples/primitives-simple.rs:17-76,
   examples/macho-cows.rs:17-128, examples/entering-the-mirror-dimension.rs:17-188,
   examples/big-scene.rs:26-109, examples/smooth-shading.rs:17-100, examples/glossy-reflection.rs:17-87,
-  examples/soft-shadows.rs:17-95, examples/hier.rs:17-101, examples/instance.rs:17-95, examples/antialiasing.rs:18-50, examples/fish.rs:17-63.
+  examples/soft-shadows.rs:17-95, examples/hier.rs:17-101, examples/instance.rs:17-95, examples/antialiasing.rs:18-50, examples/fish.rs:17-63, examples/transmission-refraction.rs:20-264.
 The product has its own C++ transliteration of the same scripts (examples/*.cpp); the tests check
 that both produce identical node matrices.
 """
@@ -307,7 +307,63 @@ def fish():
     return scene, cam, (910, 512)
 
 
-TEXTURED_EXAMPLES = {"normal-mapping": normal_mapping, "fish": fish}
+def transmission_refraction():
+    """examples/transmission-refraction.rs:20-264: a glass pane in front of a tiled water tank with two textured
+    KDMesh fish, a wooden table (texture + normal map), a glass of water with a straw."""
+    from scene_dsl import KDMesh, Texture
+    tex = lambda name: Texture.open(os.path.join(ASSETS, name))
+    WINDOW_GLASS, WATER = 1.51, 1.33  # material.rs:12-16
+    mat_glass = Material(diffuse=(0.0, 0.0, 0.0), specular=(0.3, 0.3, 0.3), shininess=25.0, reflectivity=1.0, refraction_index=WINDOW_GLASS)
+    # room()
+    mat_walls = Material(diffuse=(0.607917, 0.8, 0.551884), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    mat_table = Material(specular=(0.5, 0.5, 0.5), shininess=100.0, texture=tex("Wood_018_basecolor_cubemap.jpg"), normals=tex("Wood_018_normal_cubemap.jpg"))
+    room = Node.group([
+        Node.geo(Cube(), mat_table).scaled((20.0, 5.0, 2.5)).translated((0.0, -2.0, 1.3)),
+        Node.geo(Plane(), mat_walls).scaled((20.0, 1.0, 20.0)).rotated_x(to_radians(90.0)).translated((0.0, 3.0, -10.0)),
+        Node.geo(Plane(), mat_walls).scaled((20.0, 1.0, 12.0)).rotated_z(to_radians(90.0)).translated((10.0, 3.0, -6.0)),
+        Node.geo(Plane(), mat_walls).scaled((20.0, 1.0, 12.0)).rotated_z(to_radians(-90.0)).translated((-10.0, 3.0, -6.0)),
+        Node.geo(Plane(), mat_walls).scaled((12.1, 1.0, 20.0)).rotated_x(to_radians(90.0)).translated((16.0, 3.0, 0.0)),
+        Node.geo(Plane(), mat_walls).scaled((12.1, 1.0, 20.0)).rotated_x(to_radians(90.0)).translated((-16.0, 3.0, 0.0)),
+    ])
+    # tank()
+    mat_tank = Material(specular=(0.5, 0.5, 0.5), shininess=100.0, texture=tex("Tiles_017_basecolor_cubemap.jpg"), normals=tex("Tiles_017_normal_cubemap.jpg"))
+    nodes = []
+    for i in range(4):
+        nodes.append(Node.geo(Cube(), mat_tank).scaled((5.0, 5.0, 0.2)).translated((float(i) * 5.0 - 7.5, -2.0, -10.0)))
+        nodes.append(Node.geo(Cube(), mat_tank).scaled((5.0, 5.0, 0.2)).translated((float(i) * 5.0 - 7.5, -2.0, 0.0)))
+    for i in range(2):
+        nodes.append(Node.geo(Cube(), mat_tank).scaled((0.2, 5.0, 5.0)).translated((-10.0, -2.0, -(float(i) * 5.0 + 2.5))))
+        nodes.append(Node.geo(Cube(), mat_tank).scaled((0.2, 5.0, 5.0)).translated((10.0, -2.0, -(float(i) * 5.0 + 2.5))))
+    for x in range(4):
+        for y in range(2):
+            nodes.append(Node.geo(Cube(), mat_tank).scaled((5.0, 0.2, 5.0)).translated((float(x) * 5.0 - 7.5, -4.0, -(float(y) * 5.0 + 2.5))))
+    tank = Node.group(nodes)
+    # water()
+    mat_water = Material(diffuse=(0.0, 0.0, 0.1), specular=(0.3, 0.3, 0.3), shininess=25.0, reflectivity=0.9, refraction_index=WATER)
+    mat_fish = Material(diffuse=(0.8, 0.8, 0.8), specular=(0.3, 0.3, 0.3), shininess=25.0, texture=tex("fish.png"))
+    fish_model = load_mesh("fish.obj")
+    deg = lambda v: tuple(to_radians(a) for a in v)
+    water = Node.group([
+        Node.geo(Cube(), mat_water).scaled((19.799999, 3.8, 9.8)).translated((0.0, -2.0, -5.0)),
+        Node.geo(KDMesh(fish_model, True), mat_fish).rotated_xzy(deg((0.0, -71.8181, 30.8927))).translated((-4.798946, -0.970323, -5.246493)),
+        Node.geo(KDMesh(fish_model, True), mat_fish).rotated_xzy(deg((0.0, 108.666, -23.084))).translated((3.110451, -2.562474, -6.838645)),
+    ])
+    # drink()
+    mat_water2 = Material(diffuse=(0.0, 0.0, 0.1), specular=(0.3, 0.3, 0.3), shininess=25.0, reflectivity=0.9, refraction_index=WATER)
+    mat_straw = Material(diffuse=(0.8, 0.0, 0.0), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    drink = Node.group([
+        Node.geo(Cylinder(), mat_water2).scaled((1.0, 1.4, 1.0)).translated((-7.4, 1.2, 1.2)),
+        Node.geo(Cylinder(), mat_straw).scaled((0.1, 2.0, 0.1)).rotated_z(to_radians(28.4282)).translated((-7.565556, 1.411109, 1.1)),
+    ])
+    front_glass = Node.geo(Cube(), mat_glass).scaled((20.0, 10.0, 0.2)).translated((0.0, 5.0, 0.0))
+    scene = Scene(root=Node.group([front_glass, room, tank, water, drink]),
+                  lights=[Light(position=(0.0, 27.0, 5.0), color=(0.5, 0.5, 0.5))],
+                  ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.0, 14.658033, 27.19817), center=(0.0, -6.058867, -24.828854), fovy_degrees=23.0)
+    return scene, cam, (910, 512)
+
+
+TEXTURED_EXAMPLES = {"normal-mapping": normal_mapping, "fish": fish, "transmission-refraction": transmission_refraction}
 
 
 def big_mesh(n: int = 6):

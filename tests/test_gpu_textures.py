@@ -152,3 +152,21 @@ def test_cpp_normal_mapping_example_matches_oracle(oracle, host, H):
     assert st["hits"] == ref.stats["hits"] > 1000
     assert np.array_equal(rgb, ref.rgb)
     r.close()
+
+
+@pytest.mark.parametrize("mode", ["flat", "kd"])
+def test_transmission_refraction_matches_oracle(oracle, host, H, mode):
+    """The reference's most demanding scene script in one piece: glass and water (refraction to depth 10), textured
+    KDMesh fish, texture + normal maps on cubes, coincident faces (quirk Q13: ties decided by the last bit, so both
+    sides must round identically)."""
+    from example_scenes import TEXTURED_EXAMPLES
+    from scene_dsl import default_background
+    scene, cam, _ = TEXTURED_EXAMPLES["transmission-refraction"]()
+    w, h = 364, 204
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_KD if mode == "kd" else H.TRAVERSE_FLAT)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=2, seed=4, sample_mode=H.SAMPLE_RNG, stats=True)
+    ref = oracle.render(scene, cam, w, h, samples=2, seed=4, jitter=oracle.JITTER_RNG, mode=oracle.MODE_KD if mode == "kd" else oracle.MODE_FLAT)
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert np.array_equal(rgb, ref.rgb)
+    r.close()
