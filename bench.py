@@ -38,6 +38,7 @@ WORKLOADS = {
     "cows": ("macho-cows", 0, 1280, 720, 16),
     "primitives": ("primitives-simple", 0, 800, 600, 1),
     "triangle": ("single-triangle", 0, 256, 256, 1),
+    "aquarium": ("transmission-refraction", 0, 1920, 1080, 16),  # glass + water to depth 10, textured KDMesh fish, normal maps
     # synthetic, not reference scenes: the big-scene generator over cow.obj instances / baked triangles
     "big-mesh": ("synthetic:big-mesh", 6, 1920, 1080, 16),
     "big-soup": ("synthetic:big-soup", 6, 1920, 1080, 16),

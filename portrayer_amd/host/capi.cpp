@@ -168,6 +168,7 @@ static examples::Example make_example(const std::string& name, const std::string
     if (name == "antialiasing") return examples::antialiasing(assets);
     if (name == "fish") return examples::fish(assets);
     if (name == "normal-mapping") return examples::normal_mapping(assets);
+    if (name == "transmission-refraction") return examples::transmission_refraction(assets);
     throw std::runtime_error("unknown example scene: " + name);
 }
 
