@@ -798,6 +798,7 @@ static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream,
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     uint32_t want = (a.n_work + PT_BLOCK - 1) / PT_BLOCK;
+    if (const char* e = getenv("PORTRAYER_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));  // experiment: fewer resident lanes = smaller frame footprint
     uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
     *grid_out = grid;
     if (!launch) return hipSuccess;

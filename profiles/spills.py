@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where does hipcc spill? Compiles pt_api.hip with -g -save-temps at a given occupancy bound and
-lists scratch loads/stores of pt_render_kernel<FLAT> by source line. usage: spills.py <min_waves> [extra flags]"""
+lists scratch loads/stores of one pt_render_kernel instantiation by source line.
+usage: spills.py <min_waves or 0> [extra flags]   (env KERNEL = "MODE,STATS,TEX,WAVES", default "3,0,0,3")"""
 import collections, os, re, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tmp = "/tmp/pt_spills"
@@ -18,7 +19,8 @@ files = {}
 for l in text:
     m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
     if m: files[m.group(1)] = (m.group(3) or m.group(2))
-start = next(i for i, l in enumerate(text) if l.startswith("_Z16pt_render_kernelILi3ELb0ELb0EEv12PtRenderArgs:"))
+mode, stats, tex, waves = os.environ.get("KERNEL", "3,0,0,3").split(",")
+start = next(i for i, l in enumerate(text) if l.startswith(f"_Z16pt_render_kernelILi{mode}ELb{stats}ELb{tex}ELi{waves}EEv12PtRenderArgs:"))
 end = start
 while "s_endpgm" not in text[end]: end += 1
 loc = None; cnt = collections.Counter()
