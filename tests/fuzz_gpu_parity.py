@@ -48,8 +48,10 @@ def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
     w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (128, 96)
     bad_total = 0
+    tex_edge = 0
     for seed in range(first, first + count):
-        for kind, make in (("random", random_scene), ("extreme", extreme_scene)):
+        from test_gpu_textures import textured_scene  # random texels, normal maps, uv transforms on every primitive kind
+        for kind, make in (("random", random_scene), ("extreme", extreme_scene), ("textured", textured_scene)):
             scene, cam = make(seed)
             ps = O.pack(scene)
             hs = host_glue.host_scene(scene)
@@ -58,13 +60,15 @@ def main():
                 rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=2, seed=seed, sample_mode=H.SAMPLE_RNG, stats=True)
                 ref = O.render(ps, cam, w, h, samples=2, seed=seed, jitter=O.JITTER_RNG, mode=om, kd_depth=8)
                 bad = (rgb != ref.rgb).any(axis=2)
+                if kind == "textured" and bad.sum() <= 2:  # sphere uv goes through atan2 / acos: a last-bit difference may move a sample across a texel edge
+                    tex_edge += int(bad.sum()); bad[:] = False
                 rays_equal = all(st[k] == ref.stats[k] for k in ("primary", "shadow", "reflect", "refract", "hits"))
                 if bad.any() or not rays_equal or st["stack_overflow"]:
                     bad_total += int(bad.sum())
                     print(f"MISMATCH seed {seed} {kind} {mode}: {int(bad.sum())} pixels, rays_equal={rays_equal}, first {np.argwhere(bad)[:4].tolist()}, "
                           f"kd_plane_miss gpu {st['kd_plane_miss']} oracle {ref.stats['kd_plane_miss']}", flush=True)
                 r.close()
-    print(f"fuzz done: seeds {first}..{first + count - 1}, {bad_total} differing pixels in total")
+    print(f"fuzz done: seeds {first}..{first + count - 1}, {bad_total} differing pixels in total ({tex_edge} texel-edge pixels in textured scenes tolerated)")
 
 
 if __name__ == "__main__":
