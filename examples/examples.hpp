@@ -33,6 +33,7 @@ Example instance(const std::string& assets_dir);                 // examples/ins
 Example fish(const std::string& assets_dir);                     // examples/fish.rs (PNG texture on a mesh with `vt` records)
 Example normal_mapping(const std::string& assets_dir, math::Vec3 light_pos = math::Vec3{0.0, 8.0, 10.0});  // examples/normal-mapping.rs (JPEG textures + normal maps; its main() renders three light positions)
 Example transmission_refraction(const std::string& assets_dir);  // examples/transmission-refraction.rs (glass, water, textured KDMesh fish, normal-mapped cubes)
+Example water_glass(const std::string& assets_dir);              // examples/water-glass.rs (glossy, textured, normal-mapped table; water cylinder)
 Example antialiasing(const std::string& assets_dir);             // examples/antialiasing.rs (its main() renders twice)
 
 int run_main(Example ex);  // Image::new(..)? ; image.render::<RenderProgress, _>(..) ; image.save()

@@ -169,6 +169,7 @@ static examples::Example make_example(const std::string& name, const std::string
     if (name == "fish") return examples::fish(assets);
     if (name == "normal-mapping") return examples::normal_mapping(assets);
     if (name == "transmission-refraction") return examples::transmission_refraction(assets);
+    if (name == "water-glass") return examples::water_glass(assets);
     throw std::runtime_error("unknown example scene: " + name);
 }
 

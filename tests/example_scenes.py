@@ -4,7 +4,7 @@ Scene constants are taken from the reference's scene scripts (data, not code):
   examples/single-triangle.rs:17-58, examples/primitives-simple.rs:17-76,
   examples/macho-cows.rs:17-128, examples/entering-the-mirror-dimension.rs:17-188,
   examples/big-scene.rs:26-109, examples/smooth-shading.rs:17-100, examples/glossy-reflection.rs:17-87,
-  examples/soft-shadows.rs:17-95, examples/hier.rs:17-101, examples/instance.rs:17-95, examples/antialiasing.rs:18-50, examples/fish.rs:17-63, examples/transmission-refraction.rs:20-264.
+  examples/soft-shadows.rs:17-95, examples/hier.rs:17-101, examples/instance.rs:17-95, examples/antialiasing.rs:18-50, examples/fish.rs:17-63, examples/transmission-refraction.rs:20-264, examples/water-glass.rs:17-117.
 The product has its own C++ transliteration of the same scripts (examples/*.cpp); the tests check
 that both produce identical node matrices.
 """
@@ -363,7 +363,29 @@ def transmission_refraction():
     return scene, cam, (910, 512)
 
 
-TEXTURED_EXAMPLES = {"normal-mapping": normal_mapping, "fish": fish, "transmission-refraction": transmission_refraction}
+def water_glass():
+    """examples/water-glass.rs:17-117."""
+    from scene_dsl import Texture
+    tex = lambda name: Texture.open(os.path.join(ASSETS, name))
+    mat_wall = Material(specular=(0.3, 0.3, 0.3), shininess=25.0, texture=tex("Brick_Wall_013_COLOR.jpg"), normals=tex("Brick_Wall_013_NORM.jpg"))
+    mat_table = Material(specular=(0.5, 0.5, 0.5), shininess=100.0, reflectivity=0.2, glossy_side_length=2.0,
+                         texture=tex("Wood_018_basecolor_cubemap.jpg"), normals=tex("Wood_018_normal_cubemap.jpg"))
+    room = Node.group([
+        Node.geo(Plane(), mat_wall).scaled(10.0).rotated_x(to_radians(90.0)).translated((0.0, 1.0, -2.0)),
+        Node.geo(Cube(), mat_table).scaled((8.0, 0.4, 4.0)).translated((0.0, 0.0, -0.2)),
+    ])
+    mat_water = Material(diffuse=(0.0, 0.0, 0.1), specular=(0.3, 0.3, 0.3), shininess=25.0, reflectivity=0.9, refraction_index=1.33)
+    mat_straw = Material(diffuse=(0.8, 0.0, 0.0), specular=(0.3, 0.3, 0.3), shininess=25.0)
+    drink = Node.group([
+        Node.geo(Cylinder(), mat_water).scaled((1.0, 1.4, 1.0)).translated((0.0, 0.7, 0.0)),
+        Node.geo(Cylinder(), mat_straw).scaled((0.1, 2.0, 0.1)).rotated_z(to_radians(28.4282)).translated((-0.165556, 0.911109, 0.1)),
+    ]).translated((0.0, 0.2, 0.0))
+    scene = Scene(root=Node.group([room, drink]), lights=[Light(position=(0.0, 27.0, 5.0), color=(0.5, 0.5, 0.5))], ambient=(0.3, 0.3, 0.3))
+    cam = Camera(eye=(0.0, 3.2, 7.151111), center=(0.0, 0.091525, -5.719519), fovy_degrees=23.0)
+    return scene, cam, (910, 512)
+
+
+TEXTURED_EXAMPLES = {"normal-mapping": normal_mapping, "fish": fish, "transmission-refraction": transmission_refraction, "water-glass": water_glass}
 
 
 def big_mesh(n: int = 6):

@@ -153,6 +153,24 @@ def test_cpp_transmission_refraction_example_matches_oracle(oracle, host, H):
     r.close()
 
 
+def test_cpp_water_glass_example_matches_oracle(oracle, host, H):
+    """examples/water-glass.cpp end to end: glossy reflection draws + refraction + normal-mapped textures (JPEG, one of
+    them 1025 x 1025 with 4:2:0 chroma)."""
+    from example_scenes import TEXTURED_EXAMPLES
+    from scene_dsl import ASSETS, default_background
+    sc = host.Scene.example("water-glass", assets=ASSETS)
+    scene, cam, size = TEXTURED_EXAMPLES["water-glass"]()
+    assert sc.size == size
+    w, h = 455, 256
+    r = host.Renderer(sc, H.TRAVERSE_FLAT)
+    rgb, linear, st = r.render(sc.camera, w, h, default_background(w, h), samples=3, seed=2, sample_mode=H.SAMPLE_RNG, stats=True)
+    ref = oracle.render(scene, cam, w, h, samples=3, seed=2, jitter=oracle.JITTER_RNG, mode=oracle.MODE_FLAT)
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert np.array_equal(rgb, ref.rgb)
+    r.close()
+
+
 def test_cpp_normal_mapping_example_matches_oracle(oracle, host, H):
     """examples/normal-mapping.cpp end to end: six JPEG files (baseline and progressive) decoded by the C++ host,
     texture + normal maps on Plane, Cube and Sphere; the oracle gets the scene from the test DSL with

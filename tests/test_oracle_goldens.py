@@ -200,3 +200,45 @@ def test_golden_transmission_refraction(oracle):
 
     db = np.abs(blk(r.rgb) - blk(g)).max(axis=2)
     assert db.mean() < 1.5 and (db > 6).mean() < 0.04  # measured 0.94 / 2.5 %
+
+
+def test_golden_water_glass(oracle):
+    """render/06a_water-glass.png: glossy reflection on a textured, normal-mapped table, refraction through a water
+    cylinder. Glossy offsets, anti-aliasing and the JPEG decoder differ from the reference's run, so 8x8 block means
+    of a 4-sample render are compared (measured: mean 0.35 levels, 0.01 % of the blocks above 6)."""
+    from example_scenes import water_glass
+    scene, cam, (w, h) = water_glass()
+    g = golden("06a_water-glass.png")
+    r = oracle.render(scene, cam, w, h, mode=oracle.MODE_HIER, samples=4, jitter=oracle.JITTER_RNG, seed=1)
+    assert r.rgb.shape == g.shape and r.stats["refract"] > 500_000 and r.stats["reflect"] > 1_000_000
+
+    def blk(a, k=8):
+        hh, ww = a.shape[0] // k * k, a.shape[1] // k * k
+        return a[:hh, :ww].astype(float).reshape(hh // k, k, ww // k, k, 3).mean(axis=(1, 3))
+
+    db = np.abs(blk(r.rgb) - blk(g)).max(axis=2)
+    assert db.mean() < 0.6 and (db > 6).mean() < 0.002
+
+
+def test_hier_and_flat_differ_only_on_the_refractive_cylinder(oracle):
+    """Documents a KNOWN divergence, it does not excuse it: the reference's default traversal is
+    hierarchical, the GPU implements FLAT / KD. On water-glass the two oracle modes make different hit decisions for
+    rays leaving the water cylinder (a dielectric inside a transformed group): measured 1.94 % of the u8 pixels (up to
+    130 levels), ray counts differ. Two tiers: VISIBLE differences are confined to the cylinder's image region; outside
+    it no u8 pixel differs and the linear f64 image differs only by rounding (138 pixels, <= 1.2e-12). This test fails
+    if visible differences spread beyond that region or grow - i.e. if the divergence stops being explainable as the
+    refractive self-intersection case."""
+    from example_scenes import water_glass
+    scene, cam, (w, h) = water_glass()
+    a = oracle.render(scene, cam, w, h, mode=oracle.MODE_HIER)
+    b = oracle.render(scene, cam, w, h, mode=oracle.MODE_FLAT)
+    d = np.abs(a.rgb.astype(int) - b.rgb.astype(int)).max(axis=2)
+    assert a.stats["primary"] == b.stats["primary"]
+    assert a.stats["hits"] != b.stats["hits"], "HIER and FLAT now agree on water-glass: update DESIGN.md section 7"
+    assert 0.0 < (d > 0).mean() < 0.03
+    ys, xs = np.nonzero(d > 0)
+    assert xs.min() >= 330 and xs.max() <= 580 and ys.min() >= 180, "differences outside the water cylinder's region"
+    outside = np.ones_like(d, dtype=bool); outside[180:, 330:581] = False
+    assert not (d[outside] > 0).any(), "a u8 pixel differs outside the cylinder's region"
+    # rounding-only there: measured max 1.2e-12; 1e-9 is ~1000x that and ~1e6x below one u8 level (4e-3)
+    assert np.abs(a.linear[outside] - b.linear[outside]).max() < 1e-9
