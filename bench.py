@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="big-scene", choices=sorted(WORKLOADS))
-    ap.add_argument("--traversal", default="flat", choices=["flat", "kd"])
+    ap.add_argument("--traversal", default="flat", choices=["flat", "kd", "hier"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--samples", type=int, default=0)
@@ -135,7 +135,7 @@ def main():
         scene.camera = host_glue.cam10(dsl_cam)
     else:
         scene = host.Scene.example(example, n=n or 10)
-    traverse = H.TRAVERSE_KD if args.traversal == "kd" else H.TRAVERSE_FLAT
+    traverse = {"kd": H.TRAVERSE_KD, "hier": H.TRAVERSE_HIER}.get(args.traversal, H.TRAVERSE_FLAT)
     t_prep1 = time.perf_counter()
     renderer = host.Renderer(scene, traverse, kd_depth=10, device=device)  # flatten + build + upload: once, outside the timed region
     t_prep2 = time.perf_counter()

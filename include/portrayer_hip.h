@@ -32,12 +32,12 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 /* enum Primitive, src/primitive.rs:67-81 */
 enum { PT_PRIM_SPHERE = 0, PT_PRIM_TRIANGLE = 1, PT_PRIM_MESH = 2, PT_PRIM_KDMESH = 3, PT_PRIM_PLANE = 4, PT_PRIM_CUBE = 5, PT_PRIM_CYLINDER = 6, PT_PRIM_CONE = 7 };
 /* cargo features flat_scene / kdtree, src/render.rs:121-126 */
-enum { PT_TRAVERSE_FLAT = 1, PT_TRAVERSE_KD = 2 };
+enum { PT_TRAVERSE_FLAT = 1, PT_TRAVERSE_KD = 2, PT_TRAVERSE_HIER = 3 };
 /* sample position inside the pixel (the reference draws it from thread_rng, src/render.rs:38-39) */
 enum { PT_SAMPLE_CENTRE = 0, PT_SAMPLE_RNG = 1 };
 
@@ -113,6 +113,19 @@ typedef struct {
     const int32_t *kdm_axis; const double *kdm_plane; const int32_t *kdm_front, *kdm_back, *kdm_first, *kdm_count;
     uint32_t n_kdm_items;
     const int32_t *kdm_items;           /* triangle indices local to the mesh, in leaf Vec order            */
+    /* The scene GRAPH (ABI 4), for PT_TRAVERSE_HIER: the reference's default traversal (no `flat_scene` /
+     * `kdtree` feature) transforms the ray level by level down the hierarchy with each SceneNode's OWN inverse
+     * and carries hit point and normal back up level by level (src/scene.rs:80-120). That rounds differently
+     * from one composed matrix per flattened node, and where a ray starts on a refractive surface the
+     * difference decides hits. NULL / 0 for the other traversals. */
+    uint32_t n_graph_nodes;             /* distinct SceneNodes on the paths to the flattened nodes            */
+    const double *graph_trans;          /* n_graph_nodes x 16  SceneNode::trans        (scene.rs:150-160)     */
+    const double *graph_invtrans;       /* n_graph_nodes x 16  SceneNode::invtrans                            */
+    const double *graph_normal_trans;   /* n_graph_nodes x 16  SceneNode::normal_trans                        */
+    const uint32_t *node_chain_off;     /* n_nodes + 1: flattened node i's path is node_chain[off[i] .. off[i+1]) */
+    const uint32_t *node_chain;         /* graph node indices from the root down to the node itself           */
+    const uint32_t *node_dfs_rank;      /* n_nodes: place in depth-first order, a node before its children:   */
+                                        /*   the order in which equal hits are resolved (ray.rs:87-99 under scene.rs:95-117) */
 } pt_scene;
 
 /* The scene k-d tree the host built (KDTreeScene::from, src/kdtree/kdscene.rs:19-43), linearised;

@@ -13,7 +13,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libportrayer_hip.so")
 
-TRAVERSE_FLAT, TRAVERSE_KD = 1, 2
+TRAVERSE_FLAT, TRAVERSE_KD, TRAVERSE_HIER = 1, 2, 3
 SAMPLE_CENTRE, SAMPLE_RNG = 0, 1
 
 _dp = C.POINTER(C.c_double)
@@ -43,6 +43,9 @@ class PtScene(C.Structure):
         ("mesh_kd_root", _ip), ("mesh_kd_depth", _ip), ("mesh_kd_bounds", _dp), ("mesh_kd_bounds_invtrans", _dp),
         ("n_kdm_nodes", C.c_uint32), ("kdm_axis", _ip), ("kdm_plane", _dp), ("kdm_front", _ip), ("kdm_back", _ip), ("kdm_first", _ip), ("kdm_count", _ip),
         ("n_kdm_items", C.c_uint32), ("kdm_items", _ip),
+        # ABI 4: the scene graph, for TRAVERSE_HIER (the reference's default traversal, scene.rs:80-120)
+        ("n_graph_nodes", C.c_uint32), ("graph_trans", _dp), ("graph_invtrans", _dp), ("graph_normal_trans", _dp),
+        ("node_chain_off", _up), ("node_chain", _up), ("node_dfs_rank", _up),
     ]
 
 

@@ -47,6 +47,7 @@ __device__ __forceinline__ void pt_trace(const PtSceneView& sc, const PtRay& ray
     if (MODE == PT_MODE_KD) pt_trace_kd<STATS>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_HIER) pt_trace_flat<STATS, true, true, true>(sc, ray, any, hit, stk, cnt);
     else pt_trace_flat<STATS, true, false>(sc, ray, any, hit, stk, cnt);
 }
 
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
             bool mid = active && !(L.stage == PT_ST_NEW_SAMPLE && !L.has_ray);
             if (__any(mid)) active = mid;
         }
-        if (active) pt_lane_advance<STATS, TEX>(a, L, hit, fr, &cnt);
+        if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER>(a, L, hit, fr, &cnt);
 #ifdef PT_PHASE_TIMING
         unsigned long long c1 = __builtin_readcyclecounter();
 #endif
@@ -225,6 +226,7 @@ struct pt_context {
     PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh_items, kd, kd_items;
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, mkd, mkd_items;
     PtBuf node_box, kd_box, mkd_box, mkd_item_box;
+    PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank;  // PT_TRAVERSE_HIER: the scene graph
     PtBuf frames, accum, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
     PtSceneView view;
     bool have_scene = false;
@@ -290,7 +292,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box};
+                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -323,7 +325,11 @@ static void pt_pad_box(PtBuildBox* b, double rel) {
 
 extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, const pt_kdtree* kd) {
     if (!c || !s) return PT_ERR_ARGUMENT;
-    if (traverse != PT_TRAVERSE_FLAT && traverse != PT_TRAVERSE_KD) return pt_fail(c, PT_ERR_ARGUMENT, "traverse must be PT_TRAVERSE_FLAT or PT_TRAVERSE_KD");
+    if (traverse != PT_TRAVERSE_FLAT && traverse != PT_TRAVERSE_KD && traverse != PT_TRAVERSE_HIER)
+        return pt_fail(c, PT_ERR_ARGUMENT, "traverse must be PT_TRAVERSE_FLAT, PT_TRAVERSE_KD or PT_TRAVERSE_HIER");
+    if (traverse == PT_TRAVERSE_HIER && s->n_nodes &&
+        (!s->n_graph_nodes || !s->graph_trans || !s->graph_invtrans || !s->graph_normal_trans || !s->node_chain_off || !s->node_chain || !s->node_dfs_rank))
+        return pt_fail(c, PT_ERR_ARGUMENT, "PT_TRAVERSE_HIER needs the scene graph (graph_*, node_chain*, node_dfs_rank)");
     if (traverse == PT_TRAVERSE_KD && !kd) return pt_fail(c, PT_ERR_ARGUMENT, "PT_TRAVERSE_KD needs the host-built k-d tree");
     if (s->n_nodes && (!s->trans || !s->invtrans || !s->normal_trans || !s->prim_type || !s->prim_data || !s->prim_flags || !s->material))
         return pt_fail(c, PT_ERR_ARGUMENT, "null node array");
@@ -508,6 +514,23 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     // ---- nodes
     std::vector<double> inv(12 * (size_t)n), fwd(12 * (size_t)n), nrm(9 * (size_t)n);
     std::vector<uint32_t> info(4 * (size_t)n);
+    std::vector<double> g_inv, g_fwd, g_nrm;
+    std::vector<uint32_t> chain_off, chain, dfs_rank;
+    if (traverse == PT_TRAVERSE_HIER && n) {
+        const uint32_t g = s->n_graph_nodes;
+        g_inv.resize(12 * (size_t)g); g_fwd.resize(12 * (size_t)g); g_nrm.resize(9 * (size_t)g);
+        for (uint32_t i = 0; i < g; i++) {
+            for (int r = 0; r < 12; r++) { g_inv[12 * (size_t)i + r] = s->graph_invtrans[16 * (size_t)i + r]; g_fwd[12 * (size_t)i + r] = s->graph_trans[16 * (size_t)i + r]; }
+            for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) g_nrm[9 * (size_t)i + 3 * r + k] = s->graph_normal_trans[16 * (size_t)i + 4 * r + k];
+        }
+        chain_off.assign(s->node_chain_off, s->node_chain_off + n + 1);
+        if (chain_off[0] != 0) return pt_fail(c, PT_ERR_ARGUMENT, "node_chain_off must start at 0");
+        for (uint32_t i = 0; i < n; i++)
+            if (chain_off[i + 1] <= chain_off[i]) return pt_fail(c, PT_ERR_ARGUMENT, "every flattened node needs a non-empty path (it contains at least itself)");
+        chain.assign(s->node_chain, s->node_chain + chain_off[n]);
+        for (uint32_t id : chain) if (id >= g) return pt_fail(c, PT_ERR_ARGUMENT, "node_chain names a graph node out of range");
+        dfs_rank.assign(s->node_dfs_rank, s->node_dfs_rank + n);
+    }
     std::vector<PtBuildBox> node_box(n);
     for (uint32_t i = 0; i < n; i++) {
         for (int r = 0; r < 12; r++) { inv[12 * (size_t)i + r] = s->invtrans[16 * (size_t)i + r]; fwd[12 * (size_t)i + r] = s->trans[16 * (size_t)i + r]; }
@@ -650,6 +673,9 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         if (verbose && !device_meshes.empty()) fprintf(stderr, "[pt_scene_upload] device tree build: %zu mesh(es), %.2f ms, %d clustering rounds, depth %d\n", device_meshes.size(), device_ms, rounds, max_blas_depth);
         lap("device mesh trees");
     }
+    if ((rc = pt_upload(c, c->g_inv, g_inv)) || (rc = pt_upload(c, c->g_fwd, g_fwd)) || (rc = pt_upload(c, c->g_nrm, g_nrm)) ||
+        (rc = pt_upload(c, c->chain_off, chain_off)) || (rc = pt_upload(c, c->chain, chain)) || (rc = pt_upload(c, c->dfs_rank, dfs_rank)))
+        return rc;
     if ((rc = pt_upload(c, c->inv, inv)) || (rc = pt_upload(c, c->fwd, fwd)) || (rc = pt_upload(c, c->nrm, nrm)) ||
         (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
         (rc = pt_upload(c, c->meshes, meshes)) || (rc = pt_upload(c, c->node_box, node_box32)) || (rc = pt_upload(c, c->kd_box, kd_box32)) ||
@@ -739,6 +765,11 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.mkd_box = mkd_box.empty() || getenv("PORTRAYER_KD_NO_CULL") ? nullptr : (const float*)c->mkd_box.p;
     v.mkd_item_box = v.mkd_box ? (const float*)c->mkd_item_box.p : nullptr;
     v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
+    if (traverse == PT_TRAVERSE_HIER) {  // one kernel for every hierarchical scene (the general walker: meshes and KDMesh trees compiled in)
+        v.mode = PT_MODE_HIER;
+        v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
+        v.chain_off = (const uint32_t*)c->chain_off.p; v.chain = (const uint32_t*)c->chain.p; v.dfs_rank = (const uint32_t*)c->dfs_rank.p;
+    }
     // mesh-heavy scenes spend > 90 % of the wave cycles in the tree walk and gain from a 4th wave (big-soup 2.46 -> 2.75 Gray/s);
     // scenes with a few small meshes lose (mirror 11.8 -> 10.7, cows 8.9 -> 7.8)
     // and so does the reference's k-d tree on small scenes (mirror KD 3.8 -> 3.6) but not on big-scene (1.40 -> 1.65).
@@ -823,6 +854,7 @@ static hipError_t pt_dispatch(const PtRenderArgs& a, int waves, bool stats, int 
     if (a.scene.mode == PT_MODE_FLAT_NOMESH) return pt_dispatch_mode<PT_MODE_FLAT_NOMESH, 3>(a, stats, n_cu, stream, grid, launch);
     if (a.scene.mode == PT_MODE_KD)
         return waves == 4 ? pt_dispatch_mode<PT_MODE_KD, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_KD, 3>(a, stats, n_cu, stream, grid, launch);
+    if (a.scene.mode == PT_MODE_HIER) return pt_dispatch_mode<PT_MODE_HIER, 3>(a, stats, n_cu, stream, grid, launch);
     if (a.scene.mode == PT_MODE_FLAT_KDMESH)
         return waves == 4 ? pt_dispatch_mode<PT_MODE_FLAT_KDMESH, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_FLAT_KDMESH, 3>(a, stats, n_cu, stream, grid, launch);
     return waves == 4 ? pt_dispatch_mode<PT_MODE_FLAT, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_FLAT, 3>(a, stats, n_cu, stream, grid, launch);
@@ -1095,6 +1127,7 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     case PT_MODE_FLAT_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT_NOMESH>())); break;
     case PT_MODE_KD: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_KD>())); break;
     case PT_MODE_FLAT_KDMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT_KDMESH>())); break;
+    case PT_MODE_HIER: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER>())); break;
     default: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT>())); break;
     }
     PT_HIP(c, hipGetLastError());

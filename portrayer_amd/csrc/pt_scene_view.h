@@ -18,7 +18,7 @@
 
 #include "pt_math.h"
 
-enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2, PT_MODE_FLAT_NOMESH = 3, PT_MODE_FLAT_KDMESH = 4 };  // 3: FLAT without mesh instances; 4: FLAT with KDMesh trees (1 has Mesh only)
+enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2, PT_MODE_FLAT_NOMESH = 3, PT_MODE_FLAT_KDMESH = 4, PT_MODE_HIER = 5 };  // 3: FLAT without mesh instances; 4: FLAT with KDMesh trees (1 has Mesh only)
 
 // Two children per record so one fetch decides both sides. A child reference is one 32-bit word
 // (one traversal-stack slot): bit 31 clear = inner node index; bit 31 set = leaf with
@@ -74,6 +74,13 @@ struct PtSceneView {
     uint32_t tlas_root, pad0;
     const PtKdNode* kd;
     const uint32_t* kd_items;
+    // PT_MODE_HIER (scene.rs:80-120): each SceneNode's OWN matrices and every flattened node's path through them
+    const double* g_inv;        // per graph node: rows 0..2 of its invtrans (12)
+    const double* g_fwd;        // per graph node: rows 0..2 of its trans (12)
+    const double* g_nrm;        // per graph node: upper 3x3 of its normal_trans (9)
+    const uint32_t* chain_off;  // n_nodes + 1
+    const uint32_t* chain;      // graph node indices, root first
+    const uint32_t* dfs_rank;   // per flattened node: depth-first order, a node before its children (who wins equal hits)
     const float* kd_box;     // KD mode: per k-d node, the union of the boxes of everything below it (6 f32, rounded outward); else null
     const float* node_box;   // KD mode: per kd_items entry, that node's padded world box as 6 f32 rounded outward (leaf pre-cull in pt_trace_kd); else null
     double kd_extent;  // bounding_box.rs:95-99: squared diagonal of the root bounds

@@ -304,7 +304,7 @@ PT_NOINLINE void pt_apply_maps(const PtTexInfo* tex, const uint8_t* tex_rgb, con
 #define PT_ADVANCE_ATTR PT_HD
 #endif
 // TEX = false compiles the texture / normal-map path out (scenes without mapped materials).
-template <bool STATS, bool TEX>
+template <bool STATS, bool TEX, bool HIER = false>
 PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt) {
     const PtSceneView& sc = a.scene;
     L.has_ray = false;
@@ -408,7 +408,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             // flat_scene.rs:85-95: rebuild the model-space hit, bring point and normal to world space
             const uint32_t* info = sc.info + 4 * (size_t)hit.node;
             uint32_t type = info[0], flags = info[2], mat = info[3];
-            PtRay local = pt_ray_to_local(sc.inv + 12 * (size_t)hit.node, L.ray);
+            PtRay local = pt_node_local_ray<HIER>(sc, hit.node, L.ray);
             PtVec3 p, n;
             if (type == PT_TRIANGLE || type == PT_MESH || type == PT_KDMESH) {
                 const double* v = sc.tri_v + 9 * (size_t)hit.sub;
@@ -428,10 +428,19 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 pt_prim_surface(type, hit.sub, local, hit.t, &p, &n);
             }
             PT_FENCE;
-            PtVec3 P = pt_xform_point(sc.fwd + 12 * (size_t)hit.node, p);
+            PtVec3 P, Nw;
+            if (HIER) {  // scene.rs:100-101, :111-112: every level on the way up applies its own trans / normal_trans
+                P = p; Nw = n;
+                for (uint32_t k = sc.chain_off[hit.node + 1]; k-- > sc.chain_off[hit.node];) {
+                    P = pt_xform_point(sc.g_fwd + 12 * (size_t)sc.chain[k], P);
+                    Nw = pt_xform_dir(sc.g_nrm + 9 * (size_t)sc.chain[k], 3, Nw);
+                }
+            } else {
+                P = pt_xform_point(sc.fwd + 12 * (size_t)hit.node, p);
+            }
             fr.store3(L.depth, 3, P);
             PT_FENCE;
-            PtVec3 Nw = pt_xform_dir(sc.nrm + 9 * (size_t)hit.node, 3, n);
+            if (!HIER) Nw = pt_xform_dir(sc.nrm + 9 * (size_t)hit.node, 3, n);
             PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
             const double* m = sc.materials + 10 * (size_t)mat;
             PtVec3 kd = pt_v3(m[0], m[1], m[2]);

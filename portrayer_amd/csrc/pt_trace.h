@@ -170,6 +170,26 @@ PT_HD double pt_cand_end(const PtHit& best, uint32_t node, uint32_t sub) {
     return before ? pt_next_up(best.t) : best.t;
 }
 
+// The same for the hierarchical traversal: between different nodes the one that comes first depth-first wins
+// (scene.rs:95-117: own geometry, then the children in order, each a half-open shrinking range).
+template <bool HIER>
+PT_HD double pt_cand_end_in(const PtSceneView& sc, const PtHit& best, uint32_t node, uint32_t sub) {
+    if (!HIER) return pt_cand_end(best, node, sub);
+    bool before = best.node != PT_NO_HIT && (node == best.node ? sub < best.sub : sc.dfs_rank[node] < sc.dfs_rank[best.node]);
+    return before ? pt_next_up(best.t) : best.t;
+}
+
+// World-space ray -> the node's model space. FLAT: the flattened node's composed inverse (flat_scene.rs:74).
+// HIER: one SceneNode at a time down the path, each with its own inverse (scene.rs:82) - the same transform in
+// exact arithmetic, different roundings.
+template <bool HIER>
+PT_HD PtRay pt_node_local_ray(const PtSceneView& sc, uint32_t node, const PtRay& ray) {
+    if (!HIER) return pt_ray_to_local(sc.inv + 12 * (size_t)node, ray);
+    PtRay r = ray;
+    for (uint32_t k = sc.chain_off[node]; k < sc.chain_off[node + 1]; k++) r = pt_ray_to_local(sc.g_inv + 12 * (size_t)sc.chain[k], r);
+    return r;
+}
+
 PT_HD double pt_axis(PtVec3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
 // KDMesh::ray_hit (kdtree/kdmesh.rs:62-74): box test on the tree's root bounds, then the mesh's OWN
@@ -325,7 +345,7 @@ PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool an
 #define PT_REF_MARKER 0xFFFFFFFEu
 // MESH = false compiles the mesh-instance path out (scenes of analytic primitives and stand-alone
 // triangles only): fewer live registers in the hot loop.
-template <bool STATS, bool MESH, bool KDMESH = MESH>
+template <bool STATS, bool MESH, bool KDMESH = MESH, bool HIER = false>
 PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
     best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
     if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return false;
@@ -366,7 +386,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                 if (MESH && inst != PT_NO_HIT) {  // a triangle of the current mesh instance (mesh.rs:157-166, triangle.rs:38-80)
                     double tt, beta, gamma;
                     if (STATS) cnt->n_tri++;
-                    if (pt_triangle_hit(sc.tri_v + 9 * (size_t)item, local, PT_EPSILON, pt_cand_end(best, inst, item), &tt, &beta, &gamma)) {
+                    if (pt_triangle_hit(sc.tri_v + 9 * (size_t)item, local, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, inst, item), &tt, &beta, &gamma)) {
                         best.t = tt; best.node = inst; best.sub = item;
                         if (any) return true;
                     }
@@ -374,18 +394,18 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                 }
                 const uint32_t* info = sc.info + 4 * (size_t)item;
                 uint32_t type = info[0], data = info[1];
-                PtRay lr = pt_ray_to_local(sc.inv + 12 * (size_t)item, ray);  // flat_scene.rs:74
+                PtRay lr = pt_node_local_ray<HIER>(sc, item, ray);  // flat_scene.rs:74
                 if (STATS) cnt->n_analytic++;
                 if (MESH && KDMESH && type == PT_KDMESH && sc.meshes[data].kd_root >= 0) {  // the reference's own triangle tree (quirk Q3)
                     double t; uint32_t tri = 0;
-                    if (pt_kdmesh_hit<STATS>(sc, sc.meshes[data], lr, PT_EPSILON, pt_cand_end(best, item, 0), stk, sp, &t, &tri, cnt)) {
+                    if (pt_kdmesh_hit<STATS>(sc, sc.meshes[data], lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, item, 0), stk, sp, &t, &tri, cnt)) {
                         best.t = t; best.node = item; best.sub = tri;
                         if (any) return true;
                     }
                 } else if (MESH && (type == PT_MESH || type == PT_KDMESH)) {  // mesh.rs:146-155: box test, then the triangles
                     const PtMeshInfo& m = sc.meshes[data];
                     if (STATS) cnt->n_bbox++;
-                    if (m.blas_root == PT_REF_EMPTY || !pt_bbox_test_hit(m.bbox_inv, lr, PT_EPSILON, pt_cand_end(best, item, 0))) continue;
+                    if (m.blas_root == PT_REF_EMPTY || !pt_bbox_test_hit(m.bbox_inv, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, item, 0))) continue;
                     if (sp + 2 > stk.cap) { if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
                     // remaining items of this leaf (scene leaves hold one node unless PORTRAYER_TLAS_LEAF > 1)
                     if (i + 1 < count) pt_push(stk, sp, PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2));
@@ -398,10 +418,10 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                     if (type == PT_TRIANGLE) {
                         double beta, gamma;
                         if (STATS) cnt->n_tri++;
-                        hit = pt_triangle_hit(sc.tri_v + 9 * (size_t)data, lr, PT_EPSILON, pt_cand_end(best, item, data), &t, &beta, &gamma);
+                        hit = pt_triangle_hit(sc.tri_v + 9 * (size_t)data, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, item, data), &t, &beta, &gamma);
                         part = data;
                     } else {
-                        hit = pt_unit_prim_hit(type, lr, PT_EPSILON, pt_cand_end(best, item, 0), &t, &part);
+                        hit = pt_unit_prim_hit(type, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, item, 0), &t, &part);
                     }
                     if (hit) {
                         best.t = t; best.node = item; best.sub = part;

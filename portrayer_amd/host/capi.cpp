@@ -396,10 +396,10 @@ extern "C" int ph_obj_load(const char* path, uint64_t counts[3], double* positio
 
 extern "C" int ph_renderer_create(const ph_scene* s, int traverse, int kd_depth, int device, ph_renderer** out) {
     if (!s || !out) return bad("null argument");
-    if (traverse != PT_TRAVERSE_FLAT && traverse != PT_TRAVERSE_KD) return bad("traverse must be PT_TRAVERSE_FLAT or PT_TRAVERSE_KD");
+    if (traverse != PT_TRAVERSE_FLAT && traverse != PT_TRAVERSE_KD && traverse != PT_TRAVERSE_HIER) return bad("traverse must be PT_TRAVERSE_FLAT, PT_TRAVERSE_KD or PT_TRAVERSE_HIER");
     return guarded([&]() -> int {
         auto r = std::make_unique<ph_renderer>();
-        r->r = std::make_unique<detail::Renderer>(s->hier, traverse == PT_TRAVERSE_KD ? render::Traversal::KdTree : render::Traversal::Flat, kd_depth, device);
+        r->r = std::make_unique<detail::Renderer>(s->hier, traverse == PT_TRAVERSE_KD ? render::Traversal::KdTree : (traverse == PT_TRAVERSE_HIER ? render::Traversal::Hier : render::Traversal::Flat), kd_depth, device);
         *out = r.release();
         return PH_OK;
     });

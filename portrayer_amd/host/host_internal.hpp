@@ -27,6 +27,9 @@ BoundingBox primitive_bounds(const primitive::Primitive& p);       // Bounds for
 struct FlatSceneNode {  // flat_scene.rs:50-61
     scene::Geometry geometry;
     math::Mat4 trans, invtrans, normal_trans;
+    // not in the reference's FlatSceneNode: where the node sits in the hierarchy, for PT_TRAVERSE_HIER
+    std::vector<const scene::SceneNode*> chain;  // root .. the SceneNode that owns the geometry
+    std::vector<uint32_t> path;                  // child index taken at every step below the root
     FlatSceneNode(scene::Geometry g, const math::Mat4& t);  // flat_scene.rs:103-108
     BoundingBox bounds() const { return trans * primitive_bounds(geometry.primitive); }  // flat_scene.rs:63-69
 };

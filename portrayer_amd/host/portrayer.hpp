@@ -342,7 +342,7 @@ struct RenderProgress : Reporter {  // reporter.rs:15-85; prints a percentage li
 namespace render {  // src/render.rs
 // The reference selects the traversal at compile time with cargo features (render.rs:121-126);
 // here it is a run-time setting (default Flat; environment variable PORTRAYER_TRAVERSAL=kdtree).
-enum class Traversal { Flat = 1, KdTree = 2 };
+enum class Traversal { Flat = 1, KdTree = 2, Hier = 3 };  // the crate's `flat_scene` feature, its `kdtree` feature, its DEFAULT (neither: SceneNode::ray_cast)
 void set_traversal(Traversal t);
 Traversal traversal();
 

@@ -2,7 +2,7 @@
 """Fuzz parity run (not collected by pytest; run on the GPU box):
    python tests/fuzz_gpu_parity.py <first seed> <count> [width height]
 Random scenes (tests/test_gpu_render_parity.random_scene) with extreme scales / near-degenerate
-transforms mixed in, FLAT and KD, GPU vs oracle: reports every pixel that differs."""
+transforms mixed in, and textured scenes; FLAT, KD and HIER, GPU vs oracle: reports every pixel that differs."""
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -55,7 +55,7 @@ def main():
             scene, cam = make(seed)
             ps = O.pack(scene)
             hs = host_glue.host_scene(scene)
-            for mode, tr, om in (("flat", H.TRAVERSE_FLAT, O.MODE_FLAT), ("kd", H.TRAVERSE_KD, O.MODE_KD)):
+            for mode, tr, om in (("flat", H.TRAVERSE_FLAT, O.MODE_FLAT), ("kd", H.TRAVERSE_KD, O.MODE_KD), ("hier", H.TRAVERSE_HIER, O.MODE_HIER)):
                 r = host.Renderer(hs, tr, kd_depth=8)
                 rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=2, seed=seed, sample_mode=H.SAMPLE_RNG, stats=True)
                 ref = O.render(ps, cam, w, h, samples=2, seed=seed, jitter=O.JITTER_RNG, mode=om, kd_depth=8)

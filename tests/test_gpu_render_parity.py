@@ -322,6 +322,54 @@ def test_large_synthetic_scene_matches_oracle(oracle, host, H, name, size):
 
 
 # ---------------------------------------------------------------------------------------------------
+# hierarchical traversal = the reference's DEFAULT feature set (scene.rs:80-120): ray transformed level by level with each
+# SceneNode's own inverse, point / normal carried back up level by level, equal hits to whoever comes first depth-first.
+# Not image-equivalent to FLAT where a refractive primitive sits under a transformed group.
+# ---------------------------------------------------------------------------------------------------
+def _render_hier(oracle, host, H, scene, cam, w, h, **kw):
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_HIER)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), stats=True,
+                               **({"samples": kw["samples"], "seed": kw["seed"], "sample_mode": H.SAMPLE_RNG} if kw else {}))
+    ref = oracle.render(scene, cam, w, h, mode=oracle.MODE_HIER, **({"samples": kw["samples"], "seed": kw["seed"], "jitter": oracle.JITTER_RNG} if kw else {}))
+    r.close()
+    return rgb, linear, st, ref
+
+
+@pytest.mark.parametrize("name", ["water-glass", "transmission-refraction", "hier", "instance", "entering-the-mirror-dimension", "macho-cows", "glossy-reflection"])
+def test_hierarchical_traversal_matches_oracle(oracle, host, H, name):
+    from example_scenes import MORE_EXAMPLES, TEXTURED_EXAMPLES
+    make = {**EXAMPLES, **MORE_EXAMPLES, **TEXTURED_EXAMPLES}[name]
+    scene, cam, _ = make()
+    rgb, linear, st, ref = _render_hier(oracle, host, H, scene, cam, 364, 204, samples=2, seed=6)
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert np.array_equal(rgb, ref.rgb)
+    assert ulp_diff(linear, ref.linear).max() <= 4096
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_hierarchical_traversal_random_scenes(oracle, host, H, seed):
+    """random_scene: shared subtrees under two parents (instancing), nested transformed groups, mirrors, glass, meshes,
+    KDMeshes - the paths, the per-level matrices and the depth-first tie-break all matter."""
+    scene, cam = random_scene(seed)
+    rgb, linear, st, ref = _render_hier(oracle, host, H, scene, cam, 160, 120, samples=2, seed=seed)
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert np.array_equal(rgb, ref.rgb)
+
+
+def test_hierarchical_water_glass_is_the_default_feature_image(oracle, host, H):
+    """The point of the mode: on water-glass FLAT and the reference's default traversal give visibly different images.
+    The GPU's HIER render must be the oracle's HIER image and must NOT be its FLAT image."""
+    from example_scenes import TEXTURED_EXAMPLES
+    scene, cam, (w, h) = TEXTURED_EXAMPLES["water-glass"]()
+    rgb, linear, st, ref = _render_hier(oracle, host, H, scene, cam, w, h)
+    flat = oracle.render(scene, cam, w, h, mode=oracle.MODE_FLAT)
+    assert np.array_equal(rgb, ref.rgb) and st["hits"] == ref.stats["hits"]
+    assert st["hits"] != flat.stats["hits"] and (rgb != flat.rgb).any(axis=2).mean() > 0.01
+
+
+# ---------------------------------------------------------------------------------------------------
 # device-side tree build (pt_build.hip, SURVEY §8f-4): the tree only finds candidates, so an image
 # rendered over device-built mesh trees equals the one over host-built trees bit for bit
 # ---------------------------------------------------------------------------------------------------

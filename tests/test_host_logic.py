@@ -35,7 +35,7 @@ def test_libraries_export_every_declared_symbol():
     assert sorted(host.EXPORTS) == host_fns
     for f in host_fns:
         getattr(host.lib(), f)
-    assert _hip.lib().pt_abi_version() == 3
+    assert _hip.lib().pt_abi_version() == 4
 
 
 def assert_same_scene(a, b):
