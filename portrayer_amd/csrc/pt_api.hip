@@ -48,6 +48,7 @@ __device__ __forceinline__ void pt_trace(const PtSceneView& sc, const PtRay& ray
     else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_HIER) pt_trace_flat<STATS, true, true, true>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_HIER_NOMESH) pt_trace_flat<STATS, false, false, true>(sc, ray, any, hit, stk, cnt);
     else pt_trace_flat<STATS, true, false>(sc, ray, any, hit, stk, cnt);
 }
 
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
             bool mid = active && !(L.stage == PT_ST_NEW_SAMPLE && !L.has_ray);
             if (__any(mid)) active = mid;
         }
-        if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER>(a, L, hit, fr, &cnt);
+        if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH>(a, L, hit, fr, &cnt);
 #ifdef PT_PHASE_TIMING
         unsigned long long c1 = __builtin_readcyclecounter();
 #endif
@@ -765,8 +766,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.mkd_box = mkd_box.empty() || getenv("PORTRAYER_KD_NO_CULL") ? nullptr : (const float*)c->mkd_box.p;
     v.mkd_item_box = v.mkd_box ? (const float*)c->mkd_item_box.p : nullptr;
     v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
-    if (traverse == PT_TRAVERSE_HIER) {  // one kernel for every hierarchical scene (the general walker: meshes and KDMesh trees compiled in)
-        v.mode = PT_MODE_HIER;
+    if (traverse == PT_TRAVERSE_HIER) {  // the general walker (meshes and KDMesh trees compiled in), or its mesh-free instantiation
+        v.mode = s->n_meshes == 0 ? PT_MODE_HIER_NOMESH : PT_MODE_HIER;
         v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
         v.chain_off = (const uint32_t*)c->chain_off.p; v.chain = (const uint32_t*)c->chain.p; v.dfs_rank = (const uint32_t*)c->dfs_rank.p;
     }
@@ -854,7 +855,9 @@ static hipError_t pt_dispatch(const PtRenderArgs& a, int waves, bool stats, int 
     if (a.scene.mode == PT_MODE_FLAT_NOMESH) return pt_dispatch_mode<PT_MODE_FLAT_NOMESH, 3>(a, stats, n_cu, stream, grid, launch);
     if (a.scene.mode == PT_MODE_KD)
         return waves == 4 ? pt_dispatch_mode<PT_MODE_KD, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_KD, 3>(a, stats, n_cu, stream, grid, launch);
-    if (a.scene.mode == PT_MODE_HIER) return pt_dispatch_mode<PT_MODE_HIER, 3>(a, stats, n_cu, stream, grid, launch);
+    if (a.scene.mode == PT_MODE_HIER_NOMESH) return pt_dispatch_mode<PT_MODE_HIER_NOMESH, 3>(a, stats, n_cu, stream, grid, launch);
+    if (a.scene.mode == PT_MODE_HIER)
+        return waves == 4 ? pt_dispatch_mode<PT_MODE_HIER, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_HIER, 3>(a, stats, n_cu, stream, grid, launch);
     if (a.scene.mode == PT_MODE_FLAT_KDMESH)
         return waves == 4 ? pt_dispatch_mode<PT_MODE_FLAT_KDMESH, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_FLAT_KDMESH, 3>(a, stats, n_cu, stream, grid, launch);
     return waves == 4 ? pt_dispatch_mode<PT_MODE_FLAT, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_FLAT, 3>(a, stats, n_cu, stream, grid, launch);
@@ -1128,6 +1131,7 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     case PT_MODE_KD: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_KD>())); break;
     case PT_MODE_FLAT_KDMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT_KDMESH>())); break;
     case PT_MODE_HIER: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER>())); break;
+    case PT_MODE_HIER_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER_NOMESH>())); break;
     default: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT>())); break;
     }
     PT_HIP(c, hipGetLastError());

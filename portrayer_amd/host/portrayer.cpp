@@ -818,7 +818,7 @@ Traversal traversal() {
     if (v && (std::string(v) == "kdtree" || std::string(v) == "kd")) return Traversal::KdTree;
     if (v && (std::string(v) == "flat" || std::string(v) == "flat_scene")) return Traversal::Flat;
     // Default = the crate built with NO features: SceneNode::ray_cast on the hierarchy (scene.rs:80-120). FLAT and KD
-    // correspond to `--features flat_scene` / `--features kdtree` and are faster (big-scene: 14.2 vs 10.7 Gray/s), but
+    // correspond to `--features flat_scene` / `--features kdtree` and are faster (big-scene: 14.2 vs 11.8 Gray/s), but
     // FLAT is not image-equivalent to the default where a refractive primitive sits under a transformed group
     // (water-glass: 1.9 % of the pixels), and a drop-in must not change the picture silently.
     return Traversal::Hier;
