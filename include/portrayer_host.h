@@ -74,6 +74,11 @@ int ph_scene_export(const ph_scene *scene, double *node_trans /* x16 */, int32_t
 /* FlatScene::from (flat_scene.rs:18-46): returns the number of flat nodes; fills up to cap entries. */
 int ph_scene_flatten(const ph_scene *scene, uint32_t cap, double *trans, double *invtrans, double *normal_trans,
                      int32_t *prim_type, int32_t *material, double *bounds /* x6: min, max (flat_scene.rs:63-69) */);
+/* The hierarchy as PT_TRAVERSE_HIER takes it (pt_scene's ABI-4 arrays; scene.rs:80-120): per flattened node its path through
+ * the distinct SceneNodes (root first) and its depth-first rank; per SceneNode its OWN trans / invtrans / normal_trans.
+ * Returns the number of flattened nodes; counts = {chain entries, graph nodes}. chain_off needs node_cap + 1 entries. */
+int ph_scene_graph(const ph_scene *scene, uint32_t node_cap, uint32_t chain_cap, uint32_t graph_cap, uint32_t *chain_off, uint32_t *chain,
+                   uint32_t *dfs_rank, double *graph_trans, double *graph_invtrans, double *graph_normal_trans, uint32_t counts[2]);
 /* KDTreeScene::from (kdscene.rs:19-43), linearised like pt_kdtree. Returns the node count. */
 int ph_scene_kdtree(const ph_scene *scene, int kd_depth, uint32_t node_cap, uint32_t item_cap, int32_t *axis, double *plane,
                     int32_t *front, int32_t *back, int32_t *first, int32_t *count, int32_t *leaf_items, uint32_t *n_items,

@@ -19,7 +19,7 @@ _dp, _ip, _up, _u64p, _u8p = H._dp, H._ip, H._up, H._u64p, H._u8p
 
 EXPORTS = ["ph_last_error", "ph_scene_create", "ph_example_scene", "ph_scene_destroy", "ph_scene_counts", "ph_scene_export",
            "ph_scene_flatten", "ph_scene_kdtree", "ph_camera", "ph_obj_load", "ph_renderer_create", "ph_renderer_destroy",
-           "ph_renderer_context", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write", "ph_image_read"]
+           "ph_renderer_context", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write", "ph_image_read", "ph_scene_graph"]
 
 
 class PortrayerHostError(RuntimeError):
@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
         l.ph_example_render_to_png.restype = C.c_int
         l.ph_example_render_to_png.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_char_p]
         l.ph_png_read.restype = C.c_int; l.ph_png_read.argtypes = [C.c_char_p, _up, _u8p, C.c_uint64]
+        l.ph_scene_graph.restype = C.c_int
+        l.ph_scene_graph.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, _up, _up, _up, _dp, _dp, _dp, _up]
         l.ph_image_read.restype = C.c_int; l.ph_image_read.argtypes = [C.c_char_p, _up, _u8p, C.c_uint64]
         l.ph_png_write.restype = C.c_int; l.ph_png_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _u8p]
         _lib = l
@@ -177,6 +179,16 @@ class Scene:
         pt, mat, b = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros((n, 6))
         _check(lib().ph_scene_flatten(self._h, n, _p(tr, _dp), _p(inv, _dp), _p(nrm, _dp), _p(pt, _ip), _p(mat, _ip), _p(b, _dp)), "ph_scene_flatten")
         return dict(trans=tr.reshape(n, 4, 4), invtrans=inv.reshape(n, 4, 4), normal_trans=nrm.reshape(n, 4, 4), prim_type=pt, material=mat, bounds=b)
+
+    def graph(self) -> dict:
+        """The ABI-4 scene-graph arrays PT_TRAVERSE_HIER takes (host logic, no GPU needed)."""
+        counts = np.zeros(2, dtype=np.uint32)
+        n = _check(lib().ph_scene_graph(self._h, 0, 0, 0, None, None, None, None, None, None, _p(counts, _up)), "ph_scene_graph")
+        nc, ng = int(counts[0]), int(counts[1])
+        off, chain, rank = np.zeros(n + 1, dtype=np.uint32), np.zeros(max(nc, 1), dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint32)
+        tr, inv, nrm = np.zeros((ng, 16)), np.zeros((ng, 16)), np.zeros((ng, 16))
+        _check(lib().ph_scene_graph(self._h, n, nc, ng, _p(off, _up), _p(chain, _up), _p(rank, _up), _p(tr, _dp), _p(inv, _dp), _p(nrm, _dp), _p(counts, _up)), "ph_scene_graph")
+        return dict(chain_off=off, chain=chain[:nc], dfs_rank=rank[:n], trans=tr.reshape(ng, 4, 4), invtrans=inv.reshape(ng, 4, 4), normal_trans=nrm.reshape(ng, 4, 4))
 
     def kdtree(self, kd_depth: int = 10, node_cap: int = 1 << 16, item_cap: int = 1 << 20) -> dict:
         axis = np.zeros(node_cap, dtype=np.int32); plane = np.zeros(node_cap)

@@ -339,6 +339,26 @@ extern "C" int ph_scene_flatten(const ph_scene* s, uint32_t cap, double* trans, 
     });
 }
 
+extern "C" int ph_scene_graph(const ph_scene* s, uint32_t node_cap, uint32_t chain_cap, uint32_t graph_cap, uint32_t* chain_off, uint32_t* chain,
+                              uint32_t* dfs_rank, double* graph_trans, double* graph_invtrans, double* graph_normal_trans, uint32_t counts[2]) {
+    if (!s || !counts) return bad("null argument");
+    return guarded([&]() -> int {
+        detail::FlatScene flat = detail::FlatScene::from(s->hier);
+        detail::GraphPacking g = detail::pack_graph(flat);
+        const size_t n = flat.root.size();
+        counts[0] = (uint32_t)g.chain.size(); counts[1] = g.n_graph_nodes;
+        if (chain_off && node_cap >= n) std::memcpy(chain_off, g.chain_off.data(), (n + 1) * 4);
+        if (dfs_rank && node_cap >= n) std::memcpy(dfs_rank, g.dfs_rank.data(), n * 4);
+        if (chain && chain_cap >= g.chain.size()) std::memcpy(chain, g.chain.data(), g.chain.size() * 4);
+        if (graph_cap >= g.n_graph_nodes) {
+            if (graph_trans) std::memcpy(graph_trans, g.trans.data(), g.trans.size() * 8);
+            if (graph_invtrans) std::memcpy(graph_invtrans, g.invtrans.data(), g.invtrans.size() * 8);
+            if (graph_normal_trans) std::memcpy(graph_normal_trans, g.normal_trans.data(), g.normal_trans.size() * 8);
+        }
+        return (int)n;
+    });
+}
+
 extern "C" int ph_scene_kdtree(const ph_scene* s, int kd_depth, uint32_t node_cap, uint32_t item_cap, int32_t* axis, double* plane,
                                int32_t* front, int32_t* back, int32_t* first, int32_t* count, int32_t* leaf_items, uint32_t* n_items,
                                double root_bounds[6], int32_t* max_depth) {

@@ -41,6 +41,13 @@ struct FlatScene {  // flat_scene.rs:16
     static FlatScene from(const scene::HierScene& s);  // flat_scene.rs:18-46
 };
 
+struct GraphPacking {  // the ABI-4 scene-graph arrays of pt_scene (include/portrayer_hip.h)
+    uint32_t n_graph_nodes = 0;
+    std::vector<double> trans, invtrans, normal_trans;  // n_graph_nodes x 16
+    std::vector<uint32_t> chain_off, chain, dfs_rank;
+};
+GraphPacking pack_graph(const FlatScene& flat);
+
 struct PartitionConfig {  // leaf.rs:55-67
     size_t target_max_nodes = 3;
     long target_max_merit = 3;

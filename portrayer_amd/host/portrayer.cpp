@@ -343,6 +343,35 @@ FlatScene FlatScene::from(const scene::HierScene& hier) {
     return out;
 }
 
+// The hierarchy as PT_TRAVERSE_HIER needs it (scene.rs:80-120): every SceneNode on a path gets an index and its OWN
+// three matrices; a flattened node's chain names them root first; equal hits go to whoever comes first depth-first, a
+// node before its children - which is the lexicographic order of the child-index paths (a prefix sorts first).
+GraphPacking pack_graph(const FlatScene& flat) {
+    GraphPacking g;
+    std::map<const scene::SceneNode*, uint32_t> graph_id;
+    auto append = [](std::vector<double>& dst, const Mat4& m) { const double* p = &m.m[0][0]; dst.insert(dst.end(), p, p + 16); };
+    g.chain_off.push_back(0);
+    for (const FlatSceneNode& fn : flat.root) {
+        for (const scene::SceneNode* sn : fn.chain) {
+            auto it = graph_id.find(sn);
+            if (it == graph_id.end()) {
+                it = graph_id.emplace(sn, (uint32_t)graph_id.size()).first;
+                append(g.trans, sn->trans()); append(g.invtrans, sn->inverse_trans()); append(g.normal_trans, sn->normal_trans());
+            }
+            g.chain.push_back(it->second);
+        }
+        g.chain_off.push_back((uint32_t)g.chain.size());
+    }
+    const size_t n = flat.root.size();
+    std::vector<uint32_t> order(n);
+    g.dfs_rank.resize(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return flat.root[a].path < flat.root[b].path; });
+    for (uint32_t r = 0; r < n; r++) g.dfs_rank[order[r]] = r;
+    g.n_graph_nodes = (uint32_t)graph_id.size();
+    return g;
+}
+
 namespace {
 struct InfinitePlane {  // infinite_plane.rs:16-35
     Vec3 normal, point;
@@ -646,26 +675,10 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
             // scene.rs:80-120: the hierarchy itself. Every SceneNode on a path gets an index; a flattened node's chain
             // names them root first; equal hits go to whoever comes first depth-first, a node before its children -
             // which is the lexicographic order of the child-index paths (a prefix sorts first).
-            std::map<const scene::SceneNode*, uint32_t> graph_id;
-            std::vector<double> g_trans, g_inv, g_nrm;
-            std::vector<uint32_t> chain_off{0}, chain;
-            for (const FlatSceneNode& fn : flat_.root) {
-                for (const scene::SceneNode* sn : fn.chain) {
-                    auto it = graph_id.find(sn);
-                    if (it == graph_id.end()) {
-                        it = graph_id.emplace(sn, (uint32_t)graph_id.size()).first;
-                        auto append = [](std::vector<double>& dst, const Mat4& m) { const double* p = &m.m[0][0]; dst.insert(dst.end(), p, p + 16); };  // same layout as fn.trans above
-                        append(g_trans, sn->trans()); append(g_inv, sn->inverse_trans()); append(g_nrm, sn->normal_trans());
-                    }
-                    chain.push_back(it->second);
-                }
-                chain_off.push_back((uint32_t)chain.size());
-            }
-            std::vector<uint32_t> order(n), rank(n);
-            for (uint32_t i = 0; i < n; i++) order[i] = i;
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return flat_.root[a].path < flat_.root[b].path; });
-            for (uint32_t r = 0; r < n; r++) rank[order[r]] = r;
-            s.n_graph_nodes = (uint32_t)graph_id.size();
+            GraphPacking gp = pack_graph(flat_);
+            std::vector<double>&g_trans = gp.trans, &g_inv = gp.invtrans, &g_nrm = gp.normal_trans;
+            std::vector<uint32_t>&chain_off = gp.chain_off, &chain = gp.chain, &rank = gp.dfs_rank;
+            s.n_graph_nodes = gp.n_graph_nodes;
             s.graph_trans = g_trans.data(); s.graph_invtrans = g_inv.data(); s.graph_normal_trans = g_nrm.data();
             s.node_chain_off = chain_off.data(); s.node_chain = chain.data(); s.node_dfs_rank = rank.data();
             check(ctx_, pt_scene_upload(ctx_, &s, PT_TRAVERSE_HIER, nullptr), "pt_scene_upload");

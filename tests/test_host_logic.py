@@ -3,6 +3,7 @@ oracle and the test DSL: scene-script transliterations, builder-call composition
 bounding boxes, the k-d build, the camera, the OBJ reader, the PNG codec, and that both shared
 libraries load and export every symbol their headers declare (no GPU needed)."""
 import os
+import sys
 import re
 
 import numpy as np
@@ -166,6 +167,60 @@ def test_png_codec_roundtrip(tmp_path):
     out = np.zeros_like(g)
     assert host.lib().ph_png_read(golden.encode(), size.ctypes.data_as(host._up), out.ctypes.data_as(host._u8p), out.size) == 0
     assert np.array_equal(out, g)
+
+
+def _python_paths(arr):
+    """Independent of the C++ host: geometry-bearing paths of the hierarchy in breadth-first (FlatScene::from,
+    flat_scene.rs:24-46) and in depth-first, node-before-children (SceneNode::ray_cast, scene.rs:95-117) order."""
+    off, kids, ptype, root = arr["child_off"], arr["children"], arr["prim_type"], int(arr["root"])
+    bfs, queue = [], [(root, (root,), ())]
+    while queue:
+        node, chain, path = queue.pop(0)
+        if ptype[node] >= 0:
+            bfs.append((chain, path))
+        for k, c in enumerate(kids[off[node]:off[node + 1]]):
+            queue.append((int(c), chain + (int(c),), path + (k,)))
+    dfs = []
+
+    def walk(node, path):
+        if ptype[node] >= 0:
+            dfs.append(path)
+        for k, c in enumerate(kids[off[node]:off[node + 1]]):
+            walk(int(c), path + (k,))
+
+    walk(root, ())
+    return bfs, {p: r for r, p in enumerate(dfs)}
+
+
+@pytest.mark.parametrize("name", ["entering-the-mirror-dimension", "macho-cows", "hier", "instance", "water-glass", "random-3", "random-5"])
+def test_scene_graph_packing_for_hierarchical_traversal(oracle, name):
+    """pt_scene's ABI-4 arrays (PT_TRAVERSE_HIER) as the C++ host packs them, against a Python walk of the same
+    hierarchy and the oracle's restated vek matrices: every flattened node's chain names exactly the SceneNodes on
+    its path with their OWN matrices (not composed), inverses and normal matrices are the node's own, and the
+    depth-first rank is the order scene.rs tests candidates in - including subtrees shared by two parents."""
+    from example_scenes import TEXTURED_EXAMPLES
+    if name.startswith("random-"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_render_parity import random_scene
+        scene = random_scene(int(name.split("-")[1]))[0]
+    else:
+        scene = {**EXAMPLES, **TEXTURED_EXAMPLES}[name]()[0]
+    arr, _ = oracle.arrays_from_dsl(scene)
+    own = np.asarray(arr["node_trans"], dtype=np.float64).reshape(-1, 4, 4)
+    bfs, rank = _python_paths(arr)
+    g = host_glue.host_scene(scene).graph()
+    assert len(bfs) == len(g["dfs_rank"]) > 0
+    assert len(set(rank.values())) == len(bfs) and sorted(g["dfs_rank"].tolist()) == list(range(len(bfs)))
+    for i, (chain, path) in enumerate(bfs):
+        got = g["chain"][g["chain_off"][i]:g["chain_off"][i + 1]]
+        assert len(got) == len(chain), (i, chain)
+        for level, (gid, node) in enumerate(zip(got, chain)):
+            assert np.array_equal(g["trans"][gid], own[node]), (i, level)
+            assert np.array_equal(g["invtrans"][gid], oracle.mat4_inverse(own[node])), (i, level)
+            assert np.array_equal(g["normal_trans"][gid], oracle.mat4_inverse(own[node]).T), (i, level)
+        assert int(g["dfs_rank"][i]) == rank[path], (i, path)
+    # a SceneNode reached along two paths (instancing) is ONE entry of the matrix table
+    assert g["trans"].shape[0] <= len({n for chain, _ in bfs for n in chain})
 
 
 def _image_read(path):
