@@ -316,6 +316,21 @@ def main():
             img = np.zeros((h, w, 3), dtype=np.uint8)
             _, _, hst = renderer.render(scene.camera, w, h, bg, samples=s, seed=0, sample_mode=H.SAMPLE_RNG, into=img, want_linear=False)
             out["config"]["host_buffer_path"] = {"ms_per_frame": hst["total_ms"], "Mray_per_s": rays_frame / hst["total_ms"] / 1e3}
+        if world == 1 and args.traversal == "flat" and args.share == 1:
+            # `value` is measured in the flat_scene semantics north_star prescribes. The crate's DEFAULT feature set is the
+            # hierarchical traversal, which is not image-equivalent to it on every scene and costs more: the same
+            # frame in those semantics, measured here so that the disclosure travels with the number (never used as `value`)
+            hr = host.Renderer(scene, H.TRAVERSE_HIER, device=device)
+            himg = np.zeros((h, w, 3), dtype=np.uint8)
+            _, _, hc = hr.render(scene.camera, w, h, bg, samples=s, seed=0, sample_mode=H.SAMPLE_RNG, into=himg, want_linear=False, stats=True)
+            hier_rays = hc["primary"] + hc["shadow"] + hc["reflect"] + hc["refract"]  # its OWN count (untimed counting pass)
+            best = None
+            for _ in range(3):
+                _, _, hs = hr.render(scene.camera, w, h, bg, samples=s, seed=0, sample_mode=H.SAMPLE_RNG, into=himg, want_linear=False)
+                best = hs["kernel_ms"] if best is None else min(best, hs["kernel_ms"])
+            hr.close()
+            out["config"]["default_semantics"] = {"traversal": "hier (the crate built without features, scene.rs:80-120)", "kernel_ms_per_frame": best,
+                                                  "rays_per_frame": hier_rays, "Mray_per_s": hier_rays / best / 1e3}
         if not args.no_cpu_baseline and world == 1 and not example.startswith("synthetic:"):
             out["cpu_baseline"] = cpu_baseline(example, n, w, h, args.traversal)
     else:
