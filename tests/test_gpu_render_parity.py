@@ -358,6 +358,18 @@ def test_hierarchical_traversal_random_scenes(oracle, host, H, seed):
     assert np.array_equal(rgb, ref.rgb)
 
 
+@pytest.mark.parametrize("name,size", [("big-mesh", (96, 54)), ("big-soup", (32, 18))])
+def test_hierarchical_traversal_large_synthetic_scene(oracle, host, H, name, size):
+    """1.25 M (instanced) triangles: the hierarchical kernel's 4-waves-per-SIMD instantiation (chosen for mesh-heavy scenes)
+    and, for big-soup, a device-built triangle tree under it."""
+    from example_scenes import SYNTHETIC
+    scene, cam, _ = SYNTHETIC[name](6)
+    w, h = size
+    rgb, linear, st, ref = _render_hier(oracle, host, H, scene, cam, w, h)
+    assert st["hits"] == ref.stats["hits"] > 0 and st["shadow"] == ref.stats["shadow"]
+    assert np.array_equal(rgb, ref.rgb)
+
+
 def test_hierarchical_water_glass_is_the_default_feature_image(oracle, host, H):
     """The point of the mode: on water-glass FLAT and the reference's default traversal give visibly different images.
     The GPU's HIER render must be the oracle's HIER image and must NOT be its FLAT image."""
