@@ -205,3 +205,27 @@ def test_transmission_refraction_matches_oracle(oracle, host, H, mode):
         assert st[k] == ref.stats[k], k
     assert np.array_equal(rgb, ref.rgb)
     r.close()
+
+
+@pytest.mark.parametrize("scene_name,mode", [("textured-1", "flat"), ("textured-1", "kd"), ("transmission-refraction", "flat"),
+                                             ("transmission-refraction", "hier"), ("water-glass", "hier")])
+def test_four_wave_instantiations_of_small_scenes(oracle, host, H, monkeypatch, scene_name, mode):
+    """The render kernel is compiled for 3 and for 4 waves per SIMD and pt_scene_upload picks 4 only for mesh-heavy scenes
+    or large k-d trees, so on small scenes the 4-wave instantiations (textured, KDMesh, hierarchical with meshes, ...) never
+    run on their own. PORTRAYER_WAVES=4 forces them; results must not depend on the register budget."""
+    from example_scenes import TEXTURED_EXAMPLES
+    from scene_dsl import default_background
+    monkeypatch.setenv("PORTRAYER_WAVES", "4")
+    scene, cam = textured_scene(1) if scene_name == "textured-1" else TEXTURED_EXAMPLES[scene_name]()[:2]
+    tr, om = {"flat": (H.TRAVERSE_FLAT, oracle.MODE_FLAT), "kd": (H.TRAVERSE_KD, oracle.MODE_KD), "hier": (H.TRAVERSE_HIER, oracle.MODE_HIER)}[mode]
+    w, h = 200, 112
+    r = host.Renderer(host_glue.host_scene(scene), tr, kd_depth=5)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=2, seed=8, sample_mode=H.SAMPLE_RNG, stats=True)
+    plain, _, _ = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=2, seed=8, sample_mode=H.SAMPLE_RNG)  # the non-counting instantiation
+    ref = oracle.render(scene, cam, w, h, samples=2, seed=8, jitter=oracle.JITTER_RNG, mode=om, kd_depth=5)
+    r.close()
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert st[k] == ref.stats[k], k
+    bad = (rgb != ref.rgb).any(axis=2)
+    assert bad.sum() <= (2 if scene_name == "textured-1" else 0)  # sphere uv through atan2 / acos: see test_random_textured_scene_matches_oracle
+    assert np.array_equal(plain, rgb)
