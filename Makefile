@@ -30,6 +30,16 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 portrayer_amd/libportrayer_hip.so: $(CSRC)/pt_api.o $(CSRC)/pt_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared $^ -o $@
 
+# the device objects alone (`make -B hipobjs` = the forced recompile of __graft_entry__.build())
+hipobjs: $(CSRC)/pt_api.o $(CSRC)/pt_build.o
+
+# A/B builds made HERE (hipcc cross-compiles) and swapped in on the GPU box by profiles/*.sh:
+#   make variant NAME=diag EXTRA_HIPFLAGS=-DPT_DIAG  ->  build/variants/diag/libportrayer_hip.so
+variant:
+	@mkdir -p build/variants/$(NAME)
+	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/pt_api.hip -o build/variants/$(NAME)/pt_api.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared build/variants/$(NAME)/pt_api.o $(CSRC)/pt_build.o -o build/variants/$(NAME)/libportrayer_hip.so
+
 oracle:
 	$(MAKE) -C oracle
 
@@ -37,4 +47,4 @@ clean:
 	rm -f portrayer_amd/*.so $(CSRC)/*.o
 	rm -rf examples/bin
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean
+.PHONY: all oracle clean hipobjs variant

@@ -78,6 +78,32 @@ def measured_traffic(workload, traversal, n_gpus):
         return None
 
 
+def spawn_ranks(n):
+    """Starts `n` copies of this script as ranks 0..n-1 of one job (the environment torch.distributed.run
+    would give them, rendezvous on 127.0.0.1) and waits for them. Rank 0's stdout is passed through."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: rank(s) failed: " + ", ".join(f"rank {r} rc {rc}" for r, rc in bad), file=sys.stderr)
+        return max(abs(rc) for _, rc in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,13 +124,15 @@ def main():
     ap.add_argument("--share-rank", type=int, default=0, help="testing: which rank's tiles --share renders")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: this process becomes a launcher. It has not touched the GPU (no
+        # torch, no HIP call so far) and never will: it starts N fresh rank processes, one per GPU, relays
+        # rank 0's stdout (the JSON line) and exits with the worst return code.
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
     dist = torch = None
     use_dist = world > 1 or args.force_dist
     if use_dist:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 /* enum Primitive, src/primitive.rs:67-81 */
 enum { PT_PRIM_SPHERE = 0, PT_PRIM_TRIANGLE = 1, PT_PRIM_MESH = 2, PT_PRIM_KDMESH = 3, PT_PRIM_PLANE = 4, PT_PRIM_CUBE = 5, PT_PRIM_CYLINDER = 6, PT_PRIM_CONE = 7 };
@@ -179,6 +179,7 @@ typedef struct {
     uint64_t stack_overflow;    /* must be 0                                                              */
     double kernel_ms;           /* device time of the render kernel (HIP events)                          */
     double total_ms;            /* upload of per-call inputs + kernel + read-back                         */
+    uint64_t diag[8];           /* (ABI 5) lane-occupancy diagnostics of -DPT_DIAG builds (profiles/diag.sh); 0 otherwise */
 } pt_stats;
 
 int pt_abi_version(void);

@@ -75,10 +75,12 @@ class PtRenderParams(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("primary", "shadow", "reflect", "refract", "depth11_skipped", "hits", "n_inner", "n_leaf",
                                           "n_analytic", "n_tri", "n_bbox", "kd_plane_miss", "stack_overflow")] + \
-               [("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+               [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("diag", C.c_uint64 * 8)]
 
     def as_dict(self):
-        return {n: (float if n.endswith("_ms") else int)(getattr(self, n)) for n, _ in self._fields_}
+        d = {n: (float if n.endswith("_ms") else int)(getattr(self, n)) for n, _ in self._fields_ if n != "diag"}
+        d["diag"] = [int(x) for x in self.diag]
+        return d
 
 
 _lib: Optional[C.CDLL] = None
@@ -87,6 +89,20 @@ EXPORTS = ["pt_abi_version", "pt_device_count", "pt_context_create", "pt_context
            "pt_render", "pt_render_device", "pt_render_finish", "pt_compact_bytes", "pt_untile_device", "pt_tile_slot_pixel", "pt_untile_host", "pt_device_alloc",
            "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_synchronize", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
            "pt_test_math"]
+
+
+def header_functions():
+    """Names of the functions include/portrayer_hip.h declares (every `pt_*(` outside comments)."""
+    import re
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "portrayer_hip.h")) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", text)))
+
+
+def missing_symbols():
+    """Functions the header declares that the loaded library does not export (must be empty)."""
+    l = lib()
+    return [n for n in header_functions() if not hasattr(l, n)]
 
 
 def lib() -> C.CDLL:

@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
     stk.base = pt_lds + threadIdx.x;
     stk.stride = PT_BLOCK;
     stk.cap = a.scene.stack_cap;
+    stk.overflow = a.overflow_flag;
     const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     PtFrameRef fr;
@@ -138,9 +139,23 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
             bool mid = active && !(L.stage == PT_ST_NEW_SAMPLE && !L.has_ray);
             if (__any(mid)) active = mid;
         }
+#ifdef PT_DIAG
+        if (STATS) {
+            PtCounters* cnt_p = &cnt; (void)cnt_p;
+            if (__any(active) && lane == (unsigned)__ffsll((long long)__ballot(1)) - 1u) cnt.diag[2]++;
+            if (active) cnt.diag[3]++;
+        }
+#endif
         if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH>(a, L, hit, fr, &cnt);
 #ifdef PT_PHASE_TIMING
         unsigned long long c1 = __builtin_readcyclecounter();
+#endif
+#ifdef PT_DIAG
+        if (STATS) {
+            const bool tracing = L.work != PT_IDLE && L.has_ray;
+            if (__any(tracing) && lane == (unsigned)__ffsll((long long)__ballot(1)) - 1u) { cnt.diag[0]++; if (__ballot(tracing && L.ray_any)) cnt.diag[6]++; }
+            if (tracing) { cnt.diag[1]++; if (L.ray_any) cnt.diag[7]++; }
+        }
 #endif
         if (L.work != PT_IDLE && L.has_ray) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
 #ifdef PT_PHASE_TIMING
@@ -153,12 +168,13 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
 
 template <int MODE>
 __global__ void __launch_bounds__(PT_BLOCK) pt_cast_kernel(PtSceneView sc, uint64_t n, const double* o, const double* d, int any,
-                                                          double* out_t, int32_t* out_node, int32_t* out_sub) {
+                                                          double* out_t, int32_t* out_node, int32_t* out_sub, unsigned int* overflow) {
     extern __shared__ uint32_t pt_lds[];
     PtStack stk;
     stk.base = pt_lds + threadIdx.x;
     stk.stride = PT_BLOCK;
     stk.cap = sc.stack_cap;
+    stk.overflow = overflow;
     uint64_t i = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= n) return;
     PtRay r;
@@ -786,6 +802,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     int below = std::max(max_blas_depth, 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
     int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + below + 2 : tlas.depth + below + 4;
     v.stack_cap = std::max(cap, 8);
+    if (const char* e = getenv("PORTRAYER_STACK_CAP")) v.stack_cap = std::max(1, atoi(e));  // tests: force PT_ERR_TRAVERSAL
     if (textured) {
         v.mat_maps = (const int32_t*)c->mat_maps.p; v.uv_trans = (const double*)c->uv_trans.p; v.tex = (const PtTexInfo*)c->tex.p;
         v.tex_rgb = (const uint8_t*)c->tex_rgb.p; v.srgb_lut = (const double*)c->srgb_lut.p; v.tri_uv = (const double*)c->tri_uv.p;
@@ -819,6 +836,12 @@ static int pt_check_params(pt_context* c, const pt_camera* cam, const pt_render_
         return pt_fail(c, PT_ERR_SLICE, "slice corner outside the image (render.rs:79-90)");
     if (p->tile_ranks == 0 || p->tile_rank >= p->tile_ranks) return pt_fail(c, PT_ERR_ARGUMENT, "tile_rank must be < tile_ranks");
     if (p->sample_mode != PT_SAMPLE_CENTRE && p->sample_mode != PT_SAMPLE_RNG) return pt_fail(c, PT_ERR_ARGUMENT, "bad sample_mode");
+    // work items of one launch are indexed in 32 bits (pixel slots x 8-sample chunks): refuse what would wrap
+    if (!(p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0)) {
+        uint64_t work = (uint64_t)pt_slots_per_rank(p) * ((p->samples + PT_SAMPLE_CHUNK - 1) / PT_SAMPLE_CHUNK);
+        if (work >= 0xFFFFFFFFull - 2 * PT_WORK_BATCH_MAX)
+            return pt_fail(c, PT_ERR_ARGUMENT, "slice x samples too large for one launch (pixel slots x ceil(samples / 8) must stay below 2^32): render it in slices");
+    }
     return PT_OK;
 }
 
@@ -834,9 +857,11 @@ static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream,
     uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
     *grid_out = grid;
     if (!launch) return hipSuccess;
-    if (lds > 64 * 1024) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
+    static size_t lds_allowed = 64 * 1024;  // per instantiation: raised once, not on every launch
+    if (lds > lds_allowed) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        lds_allowed = lds;
     }
     hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
     return hipGetLastError();
@@ -895,6 +920,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.accum = (double*)c->accum.p;
     a.frames = (double*)c->frames.p;
     a.work_counter = (unsigned int*)c->misc.p;
+    a.overflow_flag = (unsigned int*)c->misc.p + 1;
     a.counters = (PtCounters*)((char*)c->misc.p + 256);
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters), stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
@@ -907,20 +933,28 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     return PT_OK;
 }
 
+// Reads back the overflow flag (always) and, for the counting build, the counters. A launch in which any lane ran
+// out of traversal stack fails with PT_ERR_TRAVERSAL whether or not the caller asked for statistics.
 static int pt_collect_stats(pt_context* c, pt_stats* st, bool counted) {
-    if (!st) return PT_OK;
-    memset(st, 0, sizeof *st);
-    float ms = 0.f;
-    PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    st->kernel_ms = ms;
-    PtCounters h;
-    PT_HIP(c, hipMemcpy(&h, (char*)c->misc.p + 256, sizeof h, hipMemcpyDeviceToHost));
-    if (counted) {
-        st->primary = h.primary; st->shadow = h.shadow; st->reflect = h.reflect; st->refract = h.refract;
-        st->depth11_skipped = h.depth11_skipped; st->hits = h.hits; st->n_inner = h.n_inner; st->n_leaf = h.n_leaf;
-        st->n_analytic = h.n_analytic; st->n_tri = h.n_tri; st->n_bbox = h.n_bbox; st->kd_plane_miss = h.kd_plane_miss;
-        st->stack_overflow = h.stack_overflow;
+    if (st) memset(st, 0, sizeof *st);
+    unsigned int head[2] = {0, 0};  // work counter, overflow flag
+    PT_HIP(c, hipMemcpy(head, c->misc.p, sizeof head, hipMemcpyDeviceToHost));
+    if (st) {
+        float ms = 0.f;
+        PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        st->kernel_ms = ms;
+        if (counted) {
+            PtCounters h;
+            PT_HIP(c, hipMemcpy(&h, (char*)c->misc.p + 256, sizeof h, hipMemcpyDeviceToHost));
+            st->primary = h.primary; st->shadow = h.shadow; st->reflect = h.reflect; st->refract = h.refract;
+            st->depth11_skipped = h.depth11_skipped; st->hits = h.hits; st->n_inner = h.n_inner; st->n_leaf = h.n_leaf;
+            st->n_analytic = h.n_analytic; st->n_tri = h.n_tri; st->n_bbox = h.n_bbox; st->kd_plane_miss = h.kd_plane_miss;
+            st->stack_overflow = h.stack_overflow;
+            for (int k = 0; k < 8; k++) st->diag[k] = h.diag[k];
+        }
+        if (head[1] && !st->stack_overflow) st->stack_overflow = 1;
     }
+    if (head[1]) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
     return PT_OK;
 }
 
@@ -950,12 +984,9 @@ extern "C" int pt_render(pt_context* c, const pt_camera* cam, const double* back
     PT_HIP(c, hipDeviceSynchronize());
     PT_HIP(c, hipMemcpy(rgb, c->rgb.p, px * 3, hipMemcpyDeviceToHost));
     if (linear) PT_HIP(c, hipMemcpy(linear, c->linear.p, px * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if ((rc = pt_collect_stats(c, stats, counted))) return rc;
-    if (stats) {
-        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (stats->stack_overflow) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
-    }
-    return PT_OK;
+    rc = pt_collect_stats(c, stats, counted);
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 extern "C" int pt_render_device(pt_context* c, const pt_camera* cam, const double* d_background, const pt_render_params* p,
@@ -984,12 +1015,8 @@ extern "C" int pt_render_finish(pt_context* c, pt_stats* stats) {
     PT_HIP(c, hipEventSynchronize(c->ev1));
     c->pending = false;
     int rc = pt_collect_stats(c, stats, c->pending_stats);
-    if (rc) return rc;
-    if (stats) {
-        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->t_start).count();
-        if (stats->stack_overflow) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
-    }
-    return PT_OK;
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->t_start).count();
+    return rc;
 }
 
 extern "C" int pt_untile_device(pt_context* c, const pt_render_params* p, const void* d_gathered, void* d_rgb, void* hip_stream) {
@@ -1110,9 +1137,18 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     if (!c->have_scene) return pt_fail(c, PT_ERR_NO_SCENE, "no scene uploaded");
     if (n == 0) return PT_OK;
     PT_HIP(c, hipSetDevice(c->device));
-    double *d_o, *d_d, *d_t; int32_t *d_n, *d_s;
-    PT_HIP(c, hipMalloc((void**)&d_o, n * 24)); PT_HIP(c, hipMalloc((void**)&d_d, n * 24)); PT_HIP(c, hipMalloc((void**)&d_t, n * 8));
-    PT_HIP(c, hipMalloc((void**)&d_n, n * 4)); PT_HIP(c, hipMalloc((void**)&d_s, n * 4));
+    struct Bufs {  // freed on every return path
+        void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Bufs() { for (void* q : p) if (q) hipFree(q); }
+    } bufs;
+    const size_t sizes[5] = {n * 24, n * 24, n * 8, n * 4, n * 4};
+    for (int k = 0; k < 5; k++) PT_HIP(c, hipMalloc(&bufs.p[k], sizes[k]));
+    double *d_o = (double*)bufs.p[0], *d_d = (double*)bufs.p[1], *d_t = (double*)bufs.p[2];
+    int32_t *d_n = (int32_t*)bufs.p[3], *d_s = (int32_t*)bufs.p[4];
+    int rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters));
+    if (rc) return rc;
+    PT_HIP(c, hipMemset(c->misc.p, 0, 8));
+    unsigned int* overflow = (unsigned int*)c->misc.p + 1;
     PT_HIP(c, hipMemcpy(d_o, origins, n * 24, hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(d_d, directions, n * 24, hipMemcpyHostToDevice));
     size_t lds = (size_t)c->view.stack_cap * PT_BLOCK * 4;
@@ -1123,7 +1159,7 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_cast_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(pt_cast_kernel<M>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s);
+        hipLaunchKernelGGL(pt_cast_kernel<M>, grid, dim3(PT_BLOCK), lds, nullptr, c->view, n, d_o, d_d, any_hit, d_t, d_n, d_s, overflow);
         return hipSuccess;
     };
     switch (c->view.mode) {
@@ -1139,7 +1175,9 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     PT_HIP(c, hipMemcpy(out_t, d_t, n * 8, hipMemcpyDeviceToHost));
     PT_HIP(c, hipMemcpy(out_node, d_n, n * 4, hipMemcpyDeviceToHost));
     PT_HIP(c, hipMemcpy(out_sub, d_s, n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_o); hipFree(d_d); hipFree(d_t); hipFree(d_n); hipFree(d_s);
+    unsigned int head[2] = {0, 0};
+    PT_HIP(c, hipMemcpy(head, c->misc.p, sizeof head, hipMemcpyDeviceToHost));
+    if (head[1]) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
     return PT_OK;
 }
 
@@ -1147,14 +1185,17 @@ extern "C" int pt_test_math(pt_context* c, int op, uint64_t n, const double* a, 
     if (!c || !a || !b || !out) return PT_ERR_ARGUMENT;
     if (n == 0) return PT_OK;
     PT_HIP(c, hipSetDevice(c->device));
-    double *d_a, *d_b, *d_o;
-    PT_HIP(c, hipMalloc((void**)&d_a, n * 8)); PT_HIP(c, hipMalloc((void**)&d_b, n * 8)); PT_HIP(c, hipMalloc((void**)&d_o, n * 8));
+    struct Bufs {
+        void* p[3] = {nullptr, nullptr, nullptr};
+        ~Bufs() { for (void* q : p) if (q) hipFree(q); }
+    } bufs;
+    for (int k = 0; k < 3; k++) PT_HIP(c, hipMalloc(&bufs.p[k], n * 8));
+    double *d_a = (double*)bufs.p[0], *d_b = (double*)bufs.p[1], *d_o = (double*)bufs.p[2];
     PT_HIP(c, hipMemcpy(d_a, a, n * 8, hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(d_b, b, n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(pt_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n, d_a, d_b, d_o);
     PT_HIP(c, hipGetLastError());
     PT_HIP(c, hipDeviceSynchronize());
     PT_HIP(c, hipMemcpy(out, d_o, n * 8, hipMemcpyDeviceToHost));
-    hipFree(d_a); hipFree(d_b); hipFree(d_o);
     return PT_OK;
 }

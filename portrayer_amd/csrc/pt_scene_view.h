@@ -110,4 +110,6 @@ struct PtCamera {  // camera.rs:17-31, built on the host (look_at inverse, tan)
 struct PtCounters {
     unsigned long long primary, shadow, reflect, refract, depth11_skipped, hits;
     unsigned long long n_inner, n_leaf, n_analytic, n_tri, n_bbox, kd_plane_miss, stack_overflow, kd_culled;
+    unsigned long long diag[8];  // -DPT_DIAG builds: 0 trace calls (per wave), 1 lanes carrying a ray into them, 2 interpreter calls (per wave),
+                                 // 3 lanes active in them, 4 inner-node steps (per wave; per lane = n_inner), 5 leaf steps (per wave; per lane = n_leaf)
 };

@@ -68,6 +68,7 @@ struct PtRenderArgs {
     double* frames;
     uint32_t n_lanes;
     unsigned int* work_counter;
+    unsigned int* overflow_flag;     // set to 1 by any lane that runs out of traversal stack
     uint32_t work_div;               // a wavefront takes (remaining work / work_div) items from work_counter at a time
     uint32_t sample_barrier;         // 1: lanes wait at the start of a sample until every lane of the wavefront is there
     PtCounters* counters;

@@ -20,12 +20,14 @@
 
 #define PT_NO_HIT 0xFFFFFFFFu
 
-// experiment (profiles/wavecount.sh): one count per WAVEFRONT pass through a place, kept in a counter the
-// scene does not otherwise use, to compare with the per-lane counts (lane occupancy of that place)
-#ifdef PT_WAVE_COUNTS
-#define PT_WAVE_COUNT(field) do { if (STATS && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt->field++; } while (0)
+// -DPT_DIAG (profiles/diag.sh): one count per WAVEFRONT pass through a place, next to the per-lane counts the
+// STATS build keeps anyway; their ratio is the lane occupancy of that place.
+#ifdef PT_DIAG
+#define PT_WAVE_COUNT(k) do { if (STATS && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt->diag[k]++; } while (0)
+#define PT_LANE_COUNT(k) do { if (STATS) cnt->diag[k]++; } while (0)
 #else
-#define PT_WAVE_COUNT(field) do { } while (0)
+#define PT_WAVE_COUNT(k) do { } while (0)
+#define PT_LANE_COUNT(k) do { } while (0)
 #endif
 
 struct PtHit {
@@ -38,7 +40,17 @@ struct PtStack {
     uint32_t* base;
     int stride;
     int cap;
+    unsigned int* overflow;  // device word set to 1 when a lane runs out of stack (PT_ERR_TRAVERSAL), in every build
 };
+// Never expected (pt_scene_upload sizes the stack for the deepest walk); recorded unconditionally so that a render
+// whose results would be wrong cannot return PT_OK.
+PT_HD void pt_stack_overflow(const PtStack& s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (s.overflow) atomicOr(s.overflow, 1u);
+#else
+    (void)s;
+#endif
+}
 
 PT_HD void pt_push(const PtStack& s, int& sp, uint32_t v) { s.base[sp * s.stride] = v; sp++; }
 PT_HD uint32_t pt_pop(const PtStack& s, int& sp) { sp--; return s.base[sp * s.stride]; }
@@ -134,7 +146,7 @@ PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, co
         while (!(cur & PT_REF_LEAF)) {
             const PtBvhNode& n = nodes[cur];
             if (STATS) cnt->n_inner++;
-            PT_WAVE_COUNT(n_tri);
+            PT_WAVE_COUNT(4);
             // tmax rounded up: (float) rounds to nearest, one more relative step covers it (inf stays inf)
             float tm = (float)tmax; tm = tm + fabsf(tm) * 2.4e-7f;
             float t0, t1;
@@ -143,7 +155,7 @@ PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, co
             uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
-                if (sp + 1 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 1 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
                 pt_push(stk, sp, swap ? c0 : c1);
                 cur = swap ? c1 : c0;
             } else if (h0) {
@@ -156,7 +168,7 @@ PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, co
             }
         }
         if (STATS) cnt->n_leaf++;
-        PT_WAVE_COUNT(n_bbox);
+        PT_WAVE_COUNT(5);
         if (leaf((cur & ~PT_REF_LEAF) >> 3, (cur & 7u) + 1u, sp)) return true;
         if (sp == sp0) return false;
         cur = pt_pop(stk, sp);
@@ -240,7 +252,7 @@ PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay
             if (s == e) { cur = s ? n.front : n.back; continue; }
             double plane_t = (n.plane - o) / d;
             if (pt_in_range(start, end, plane_t)) {
-                if (sp + 3 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 3 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
                 pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));  // pending far side: (node, start = plane_t)
                 pt_push_f64(stk, sp, plane_t);
                 cur = s ? n.front : n.back;
@@ -358,6 +370,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
         while (!(cur & PT_REF_LEAF)) {
             const PtBvhNode& n = sc.bvh[cur];
             if (STATS) cnt->n_inner++;
+            PT_WAVE_COUNT(4);
             float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;
             float t0, t1;
             bool h0 = pt_slab32(n.lo0, n.hi0, q, tm, &t0);
@@ -365,7 +378,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
             uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
-                if (sp + 1 > stk.cap) { if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
+                if (sp + 1 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
                 pt_push(stk, sp, swap ? c0 : c1);
                 cur = swap ? c1 : c0;
             } else if (h0) {
@@ -379,6 +392,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
         }
         if (cur != PT_REF_EMPTY && cur != PT_REF_MARKER) {
             if (STATS) cnt->n_leaf++;
+            PT_WAVE_COUNT(5);
             const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
             bool entered = false;
             for (uint32_t i = 0; i < count && !entered; i++) {
@@ -406,7 +420,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                     const PtMeshInfo& m = sc.meshes[data];
                     if (STATS) cnt->n_bbox++;
                     if (m.blas_root == PT_REF_EMPTY || !pt_bbox_test_hit(m.bbox_inv, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, item, 0))) continue;
-                    if (sp + 2 > stk.cap) { if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
+                    if (sp + 2 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
                     // remaining items of this leaf (scene leaves hold one node unless PORTRAYER_TLAS_LEAF > 1)
                     if (i + 1 < count) pt_push(stk, sp, PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2));
                     pt_push(stk, sp, PT_REF_MARKER);
@@ -493,7 +507,7 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
             if (s == e) { cur = s ? n.front : n.back; continue; }
             double plane_t = (n.plane - o) / d;                              // node.rs:90-109
             if (pt_in_range(start, end, plane_t)) {
-                if (sp + 3 > stk.cap) { if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 3 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
                 pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));
                 pt_push_f64(stk, sp, plane_t);
                 cur = s ? n.front : n.back;

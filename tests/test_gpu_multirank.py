@@ -1,0 +1,117 @@
+"""The multi-rank PRODUCT path on one GPU: pt_render_device(compact=1) for every rank of a tile partition,
+the rank-major concatenation a gather produces, pt_untile_device -> must equal the single-launch image
+(the compact indexing of pt_finish_kernel, pt_render_finish and pt_untile_kernel are otherwise reached
+only through bench.py). Also: the launch-size guard and the unconditional stack-overflow report."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from scene_dsl import ASSETS, default_background
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def H():
+    from portrayer_amd import _hip
+    return _hip
+
+
+@pytest.fixture(scope="module")
+def host():
+    from portrayer_amd import host
+    return host
+
+
+def render_partition(H, host, renderer, scene, w, h, rect, ranks, samples, bg):
+    """Every rank's compact buffer rendered on this GPU, concatenated rank-major, untiled on the device."""
+    lib, ctx = H.lib(), renderer.context
+    cam = host.camera(scene.camera, w, h)
+
+    def check(rc, what):
+        assert rc == 0, f"{what}: {rc} {lib.pt_last_error(ctx).decode()}"
+
+    d_bg = C.c_void_p()
+    check(lib.pt_device_alloc(ctx, bg.nbytes, C.byref(d_bg)), "alloc")
+    check(lib.pt_copy_to_device(ctx, d_bg, bg.ctypes.data_as(C.c_void_p), bg.nbytes), "copy")
+    p0 = H.PtRenderParams(w, h, H.PtRect(*rect), samples, 3, H.SAMPLE_RNG, 1, 0, ranks, 0)
+    per = int(lib.pt_compact_bytes(C.byref(p0)))
+    d_gath, d_full = C.c_void_p(), C.c_void_p()
+    check(lib.pt_device_alloc(ctx, per * ranks, C.byref(d_gath)), "alloc")
+    check(lib.pt_device_alloc(ctx, w * h * 3, C.byref(d_full)), "alloc")
+    start = np.full((h, w, 3), 7, dtype=np.uint8)  # pixels outside the slice must keep these bytes
+    check(lib.pt_copy_to_device(ctx, d_full, start.ctypes.data_as(C.c_void_p), start.nbytes), "copy")
+    rays = 0
+    for r in range(ranks):
+        p = H.PtRenderParams(w, h, H.PtRect(*rect), samples, 3, H.SAMPLE_RNG, 1, r, ranks, 1)
+        st = H.PtStats()
+        check(lib.pt_render_device(ctx, C.byref(cam), d_bg, C.byref(p), 1, C.c_void_p(d_gath.value + r * per), None), "pt_render_device")
+        check(lib.pt_render_finish(ctx, C.byref(st)), "pt_render_finish")
+        rays += st.primary + st.shadow + st.reflect + st.refract
+    check(lib.pt_untile_device(ctx, C.byref(p0), d_gath, d_full, None), "pt_untile_device")
+    check(lib.pt_synchronize(ctx), "sync")
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    check(lib.pt_copy_from_device(ctx, img.ctypes.data_as(C.c_void_p), d_full, img.nbytes), "copy back")
+    for d in (d_bg, d_gath, d_full):
+        lib.pt_device_free(ctx, d)
+    return img, rays
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+@pytest.mark.parametrize("w,h,rect", [(200, 120, (0, 0, 199, 119)), (157, 93, (11, 5, 149, 90))])
+def test_partition_assembles_to_the_single_launch_image(H, host, ranks, w, h, rect):
+    sc = host.Scene.example("entering-the-mirror-dimension", assets=ASSETS)
+    r = host.Renderer(sc, H.TRAVERSE_FLAT)
+    bg = default_background(w, h)
+    img, rays = render_partition(H, host, r, sc, w, h, rect, ranks, 9, bg)  # 9 samples: two chunks, the second partial
+    one = np.full((h, w, 3), 7, dtype=np.uint8)
+    _, _, st = r.render(sc.camera, w, h, bg, samples=9, seed=3, sample_mode=H.SAMPLE_RNG, rect=rect, into=one, want_linear=False, stats=True)
+    assert np.array_equal(img, one)
+    assert rays == st["primary"] + st["shadow"] + st["reflect"] + st["refract"]
+    x0, y0, x1, y1 = rect
+    outside = np.ones((h, w), dtype=bool); outside[y0:y1 + 1, x0:x1 + 1] = False
+    assert (img[outside] == 7).all()
+    r.close()
+
+
+def test_launch_size_guard(H, host):
+    """pixel slots x ceil(samples / 8) is a 32-bit index: what would wrap is refused, not rendered wrongly."""
+    sc = host.Scene.example("single-triangle", assets=ASSETS)
+    r = host.Renderer(sc, H.TRAVERSE_FLAT)
+    lib, ctx = H.lib(), r.context
+    w, h = 7680, 4320
+    cam = host.camera(sc.camera, w, h)
+    p = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), 1100, 0, H.SAMPLE_CENTRE, 1, 0, 1, 0)  # 33.2 M slots x 138 chunks > 2^32
+    rc = lib.pt_render_device(ctx, C.byref(cam), C.c_void_p(16), C.byref(p), 0, C.c_void_p(16), None)
+    assert rc == -1 and b"too large" in lib.pt_last_error(ctx)
+    r.close()
+
+
+_OVERFLOW = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from portrayer_amd import _hip as H, host
+from scene_dsl import ASSETS, default_background
+sc = host.Scene.example("big-scene", assets=ASSETS)
+r = host.Renderer(sc, H.TRAVERSE_FLAT)
+try:
+    r.render(sc.camera, 64, 48, default_background(64, 48), stats=False, want_linear=False)
+    print("NO ERROR")
+except Exception as e:
+    print("ERR", e)
+"""
+
+
+def test_stack_overflow_is_reported_without_the_counting_build(H):
+    """PORTRAYER_STACK_CAP=2 makes the walk of a 1000-node scene run out of stack: the plain (non-STATS)
+    kernel must fail the render with PT_ERR_TRAVERSAL (-6)."""
+    env = dict(os.environ, PORTRAYER_STACK_CAP="2")
+    out = subprocess.run([sys.executable, "-c", _OVERFLOW % (ROOT, HERE)], env=env, capture_output=True, text=True, timeout=300)
+    assert "ERR" in out.stdout and "-6" in out.stdout and "overflow" in out.stdout, out.stdout + out.stderr
