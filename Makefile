@@ -23,28 +23,38 @@ examples/bin/%: examples/%.cpp portrayer_amd/libportrayer_host.so
 	@mkdir -p examples/bin
 	$(CXX) $(CXXFLAGS) -fPIE -DPORTRAYER_EXAMPLE_MAIN $< -o $@ -Lportrayer_amd -lportrayer_host -lportrayer_hip -Wl,-rpath,'$$ORIGIN/../../portrayer_amd'
 
-# two translation units (render path / device-side tree build), compiled side by side under make -j
-$(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+# Device objects: the C ABI + small kernels, the device-side tree build, and the render kernel instantiated per
+# traversal mode (one source, six objects) - compiled side by side under make -j.
+OBJDIR ?= $(CSRC)
+HIPLIB ?= portrayer_amd/libportrayer_hip.so
+RENDER_MODES := 1 2 3 4 5 6
+HIP_OBJS := $(OBJDIR)/pt_api.o $(OBJDIR)/pt_build.o $(foreach m,$(RENDER_MODES),$(OBJDIR)/pt_render_m$(m).o)
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-portrayer_amd/libportrayer_hip.so: $(CSRC)/pt_api.o $(CSRC)/pt_build.o
+$(OBJDIR)/pt_render_m%.o: $(CSRC)/pt_render_inst.hip $(HIP_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DPT_INST_MODE=$* -c $< -o $@
+
+$(HIPLIB): $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared $^ -o $@
 
 # the device objects alone (`make -B hipobjs` = the forced recompile of __graft_entry__.build())
-hipobjs: $(CSRC)/pt_api.o $(CSRC)/pt_build.o
+hipobjs: $(HIP_OBJS)
 
 # A/B builds made HERE (hipcc cross-compiles) and swapped in on the GPU box by profiles/*.sh:
 #   make variant NAME=diag EXTRA_HIPFLAGS=-DPT_DIAG  ->  build/variants/diag/libportrayer_hip.so
 variant:
-	@mkdir -p build/variants/$(NAME)
-	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/pt_api.hip -o build/variants/$(NAME)/pt_api.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared build/variants/$(NAME)/pt_api.o $(CSRC)/pt_build.o -o build/variants/$(NAME)/libportrayer_hip.so
+	$(MAKE) OBJDIR=build/variants/$(NAME) HIPLIB=build/variants/$(NAME)/libportrayer_hip.so EXTRA_HIPFLAGS="$(EXTRA_HIPFLAGS)" build/variants/$(NAME)/libportrayer_hip.so
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
 	rm -f portrayer_amd/*.so $(CSRC)/*.o
+	rm -rf build/variants
 	rm -rf examples/bin
 	$(MAKE) -C oracle clean
 .PHONY: all oracle clean hipobjs variant

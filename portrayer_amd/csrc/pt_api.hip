@@ -1,18 +1,6 @@
-// gfx950 kernels and the C ABI declared in include/portrayer_hip.h.
-//
-// Kernel design (CDNA4: 64-wide wavefronts, 256 CUs in 8 XCDs, 160 KB LDS per CU, no matrix cores
-// involved — there is no dense contraction on this path):
-//  * persistent wavefronts: the grid is sized to what is resident on the chip; every lane owns one
-//    pixel at a time and loops over its samples in order (render.rs:36-43 summed in ascending
-//    order), then pulls the next pixel of the launch's 8x8-tile work list. Idle lanes are counted
-//    with __ballot / __popcll and ONE atomicAdd per wavefront hands out the next slots.
-//  * one traversal loop per wavefront for all ray kinds: pt_lane_advance() turns whatever the
-//    lane traced last (primary, shadow, reflected, refracted) into its next ray, so secondary rays
-//    re-enter the same loop instead of recursing (material.rs:242-243, :302-303).
-//  * traversal stack in LDS, one 32-bit column per lane (bank-conflict free by construction);
-//    recursion frames in HBM, SoA over lanes.
-//  * the scene stays resident in HBM / L2 after pt_scene_upload; a render moves only the camera
-//    (kernel argument), the background rows and the finished pixels.
+// The C ABI declared in include/portrayer_hip.h: context, scene upload (tree builds), render calls, and the
+// small kernels around the render kernel (finishing pass, untile, explicit-ray casts for the parity tests).
+// The render kernel itself is in pt_render_kernel.h, instantiated per traversal mode by pt_render_inst.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,153 +14,18 @@
 #include "../../include/portrayer_hip.h"
 #include "pt_build.h"
 #include "pt_bvh.h"
+#include "pt_render_inst.h"
 #include "pt_shade.h"
-
-#define PT_BLOCK 256
-#ifndef PT_WORK_BATCH_MAX
-#define PT_WORK_BATCH_MAX 256  // most work items a wavefront takes from the global counter at a time
-#endif
-// Waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument) is a
-// template parameter of the render kernel: 3 (168 VGPRs) where shading weighs in, 4 (128 VGPRs, more
-// spills, more latency hiding) where the tree walk dominates - chosen per scene in pt_scene_upload.
-#ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 0  // experiments: force one value for every scene (profiles/ab.sh)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Kernels
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool STATS>
-__device__ __forceinline__ void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const PtStack& stk, PtCounters* cnt) {
-    if (MODE == PT_MODE_KD) pt_trace_kd<STATS>(sc, ray, any, hit, stk, cnt);
-    else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
-    else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);
-    else if (MODE == PT_MODE_HIER) pt_trace_flat<STATS, true, true, true>(sc, ray, any, hit, stk, cnt);
-    else if (MODE == PT_MODE_HIER_NOMESH) pt_trace_flat<STATS, false, false, true>(sc, ray, any, hit, stk, cnt);
-    else pt_trace_flat<STATS, true, false>(sc, ray, any, hit, stk, cnt);
-}
-
-__device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCounters& c) {
-    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&c);
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
-    for (unsigned i = 0; i < sizeof(PtCounters) / sizeof(unsigned long long); i++)
-        if (s[i]) atomicAdd(d + i, s[i]);
-}
-
-template <int MODE, bool STATS, bool TEX, int WAVES>
-__global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES) pt_render_kernel(PtRenderArgs a) {
-    extern __shared__ uint32_t pt_lds[];
-    PtStack stk;
-    stk.base = pt_lds + threadIdx.x;
-    stk.stride = PT_BLOCK;
-    stk.cap = a.scene.stack_cap;
-    stk.overflow = a.overflow_flag;
-    const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
-    const unsigned lane = threadIdx.x & 63u;
-    PtFrameRef fr;
-    fr.base = a.frames + lane_global;
-    fr.n_lanes = a.n_lanes;
-
-    PtCounters cnt;
-    if (STATS) memset(&cnt, 0, sizeof cnt);
-    PtLane L;
-    L.work = PT_IDLE; L.has_ray = false; L.ray_any = false;
-    L.x = L.y = L.sample = L.sample_end = L.stage = L.light = L.draw = 0; L.depth = 0;
-    L.ray.o = L.ray.d = pt_v3(0.0, 0.0, 0.0);
-    PtHit hit;
-    hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
-    bool exhausted = false;
-#ifdef PT_PHASE_TIMING
-    unsigned long long c_prev = __builtin_readcyclecounter();
-#endif
-    unsigned q_next = 0, q_end = 0, q_seen = 0;  // this wavefront's private batch of work items; highest item index seen handed out
-
-    for (;;) {
-        // Hand out work items to idle lanes. Each wavefront keeps a private batch [q_next, q_end) of
-        // consecutive items (wave-uniform values) and only goes to the global counter,
-        // with ONE atomicAdd per wavefront, when the batch runs out: a device-scope atomic round trip
-        // stalls the whole wavefront, and with several lanes per pixel some lane finishes almost every
-        // iteration.
-        bool need = L.work == PT_IDLE && !exhausted;
-        unsigned long long mask = __ballot(need);
-        if (mask) {
-            unsigned count = (unsigned)__popcll(mask);
-            unsigned avail = q_end - q_next;
-            unsigned base2 = 0, take = 0;
-            if (count > avail) {
-                // guided batch size: large while plenty of work remains, exactly what is needed near the end
-                unsigned remaining = a.n_work > q_seen ? a.n_work - q_seen : 0u;
-                unsigned b = (remaining / a.work_div) & ~63u;
-                take = b > PT_WORK_BATCH_MAX ? PT_WORK_BATCH_MAX : b;
-                if (take < count - avail) take = count - avail;
-                unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
-                if (lane == leader) base2 = atomicAdd(a.work_counter, take);
-                base2 = __shfl(base2, (int)leader);
-                q_seen = base2 + take;
-            }
-            if (need) {
-                unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                unsigned w = rank < avail ? q_next + rank : base2 + (rank - avail);
-                if (w >= a.n_work) {
-                    exhausted = true;
-                } else {
-                    uint32_t x, y, chunk;
-                    if (pt_work_to_pixel(a, w, &x, &y, &chunk)) {
-                        L.work = w; L.x = x; L.y = y; L.stage = PT_ST_NEW_SAMPLE;
-                        L.sample = chunk * PT_SAMPLE_CHUNK;
-                        L.sample_end = min(a.samples, L.sample + PT_SAMPLE_CHUNK);
-                    }
-                }
-            }
-            if (count > avail) { q_next = base2 + (count - avail); q_end = base2 + take; }
-            else q_next += count;
-        }
-        bool active = L.work != PT_IDLE;
-        if (!__any(active || !exhausted)) break;
-#ifdef PT_PHASE_TIMING  // experiment (profiles/phase.sh): wave cycles spent shading / tracing / handing out work, reported in n_tri / n_bbox / kd_plane_miss
-        unsigned long long c0 = __builtin_readcyclecounter();
-#endif
-        if (a.sample_barrier) {
-            // Lanes that are about to start a sample wait until no lane of the wavefront is in the middle of
-            // one: the rays a wavefront traces together are then of one kind (64 neighbouring primary rays,
-            // then their shadow rays to light 0, ...) and walk the trees together.
-            bool mid = active && !(L.stage == PT_ST_NEW_SAMPLE && !L.has_ray);
-            if (__any(mid)) active = mid;
-        }
-#ifdef PT_DIAG
-        if (STATS) {
-            PtCounters* cnt_p = &cnt; (void)cnt_p;
-            if (__any(active) && lane == (unsigned)__ffsll((long long)__ballot(1)) - 1u) cnt.diag[2]++;
-            if (active) cnt.diag[3]++;
-        }
-#endif
-        if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH>(a, L, hit, fr, &cnt);
-#ifdef PT_PHASE_TIMING
-        unsigned long long c1 = __builtin_readcyclecounter();
-#endif
-#ifdef PT_DIAG
-        if (STATS) {
-            const bool tracing = L.work != PT_IDLE && L.has_ray;
-            if (__any(tracing) && lane == (unsigned)__ffsll((long long)__ballot(1)) - 1u) { cnt.diag[0]++; if (__ballot(tracing && L.ray_any)) cnt.diag[6]++; }
-            if (tracing) { cnt.diag[1]++; if (L.ray_any) cnt.diag[7]++; }
-        }
-#endif
-        if (L.work != PT_IDLE && L.has_ray) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
-#ifdef PT_PHASE_TIMING
-        unsigned long long c2 = __builtin_readcyclecounter();
-        if (STATS) { cnt.n_tri += c1 - c0; cnt.n_bbox += c2 - c1; cnt.kd_plane_miss += c0 - c_prev; c_prev = c2; }
-#endif
-    }
-    if (STATS) pt_flush_counters(a.counters, cnt);
-}
-
 template <int MODE>
 __global__ void __launch_bounds__(PT_BLOCK) pt_cast_kernel(PtSceneView sc, uint64_t n, const double* o, const double* d, int any,
                                                           double* out_t, int32_t* out_node, int32_t* out_sub, unsigned int* overflow) {
     extern __shared__ uint32_t pt_lds[];
     PtStack stk;
     stk.base = pt_lds + threadIdx.x;
-    stk.stride = PT_BLOCK;
     stk.cap = sc.stack_cap;
     stk.overflow = overflow;
     uint64_t i = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
@@ -244,7 +97,8 @@ struct pt_context {
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, mkd, mkd_items;
     PtBuf node_box, kd_box, mkd_box, mkd_item_box;
     PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank;  // PT_TRAVERSE_HIER: the scene graph
-    PtBuf frames, accum, bg, rgb, linear, misc;  // misc: work counter (4 B) + PtCounters
+    PtBuf spill, stack_spill, accum, bg, rgb, linear, misc;  // misc: work counter + overflow flag (8 B), PtCounters at +256
+    bool needs_spill = false;  // some material is reflective (recursion frames) or the scene has more than 32 lights
     PtSceneView view;
     bool have_scene = false;
     int waves = 3;  // occupancy variant of the render kernel for this scene (pt_dispatch)
@@ -309,7 +163,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->frames, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank};
+                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -700,6 +554,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         (rc = pt_upload(c, c->mkd_items, mkd_items)) || (rc = pt_upload(c, c->mkd_box, mkd_box)) || (rc = pt_upload(c, c->mkd_item_box, mkd_item_box)))
         return rc;
     std::vector<double> mats(s->materials, s->materials + 10 * (size_t)s->n_materials);
+    c->needs_spill = s->n_lights > PT_LIGHT_ROUND;
+    for (uint32_t m = 0; m < s->n_materials; m++) if (mats[10 * (size_t)m + 7] > 0.0) c->needs_spill = true;  // material.rs:216: reflectivity > 0 spawns children
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
     if ((rc = pt_upload(c, c->materials, mats)) || (rc = pt_upload(c, c->lights, lights))) return rc;
 
@@ -808,7 +664,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         v.tex_rgb = (const uint8_t*)c->tex_rgb.p; v.srgb_lut = (const double*)c->srgb_lut.p; v.tri_uv = (const double*)c->tri_uv.p;
     }
     lap("upload the rest");
-    if ((size_t)v.stack_cap * PT_BLOCK * 4 > 150 * 1024) return pt_fail(c, PT_ERR_SCENE, "traversal stack would not fit in LDS (tree too deep)");
+    if (v.stack_cap > 4096) return pt_fail(c, PT_ERR_SCENE, "tree too deep for the traversal stack");
     c->have_scene = true;
     return PT_OK;
 }
@@ -839,53 +695,23 @@ static int pt_check_params(pt_context* c, const pt_camera* cam, const pt_render_
     // work items of one launch are indexed in 32 bits (pixel slots x 8-sample chunks): refuse what would wrap
     if (!(p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0)) {
         uint64_t work = (uint64_t)pt_slots_per_rank(p) * ((p->samples + PT_SAMPLE_CHUNK - 1) / PT_SAMPLE_CHUNK);
-        if (work >= 0xFFFFFFFFull - 2 * PT_WORK_BATCH_MAX)
+        if (work >= 0xFFFFFFFFull - 65536)
             return pt_fail(c, PT_ERR_ARGUMENT, "slice x samples too large for one launch (pixel slots x ceil(samples / 8) must stay below 2^32): render it in slices");
     }
     return PT_OK;
 }
 
-template <int MODE, bool STATS, bool TEX, int WAVES>
-static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
-    size_t lds = (size_t)a.scene.stack_cap * PT_BLOCK * 4;
-    int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX, WAVES>, PT_BLOCK, lds);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
-    uint32_t want = (a.n_work + PT_BLOCK - 1) / PT_BLOCK;
-    if (const char* e = getenv("PORTRAYER_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));  // experiment: fewer resident lanes = smaller frame footprint
-    uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
-    *grid_out = grid;
-    if (!launch) return hipSuccess;
-    static size_t lds_allowed = 64 * 1024;  // per instantiation: raised once, not on every launch
-    if (lds > lds_allowed) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_allowed = lds;
-    }
-    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
-    return hipGetLastError();
-}
-
-template <int MODE, int WAVES>
-static hipError_t pt_dispatch_mode(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
-    const bool tex = a.scene.mat_maps != nullptr;
-    if (tex) return stats ? pt_launch<MODE, true, true, WAVES>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true, WAVES>(a, n_cu, stream, grid, launch);
-    return stats ? pt_launch<MODE, true, false, WAVES>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false, WAVES>(a, n_cu, stream, grid, launch);
-}
-
-// `waves` = pt_context::waves (3 or 4). Scenes of analytic primitives always take 3 and the
-// others as pt_scene_upload decided (measured: big-scene 14.2 vs 13.0 Gray/s at 3 vs 4).
+// `waves` = pt_context::waves (3 or 4 per SIMD, chosen per scene in pt_scene_upload).
 static hipError_t pt_dispatch(const PtRenderArgs& a, int waves, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
-    if (a.scene.mode == PT_MODE_FLAT_NOMESH) return pt_dispatch_mode<PT_MODE_FLAT_NOMESH, 3>(a, stats, n_cu, stream, grid, launch);
-    if (a.scene.mode == PT_MODE_KD)
-        return waves == 4 ? pt_dispatch_mode<PT_MODE_KD, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_KD, 3>(a, stats, n_cu, stream, grid, launch);
-    if (a.scene.mode == PT_MODE_HIER_NOMESH) return pt_dispatch_mode<PT_MODE_HIER_NOMESH, 3>(a, stats, n_cu, stream, grid, launch);
-    if (a.scene.mode == PT_MODE_HIER)
-        return waves == 4 ? pt_dispatch_mode<PT_MODE_HIER, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_HIER, 3>(a, stats, n_cu, stream, grid, launch);
-    if (a.scene.mode == PT_MODE_FLAT_KDMESH)
-        return waves == 4 ? pt_dispatch_mode<PT_MODE_FLAT_KDMESH, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_FLAT_KDMESH, 3>(a, stats, n_cu, stream, grid, launch);
-    return waves == 4 ? pt_dispatch_mode<PT_MODE_FLAT, 4>(a, stats, n_cu, stream, grid, launch) : pt_dispatch_mode<PT_MODE_FLAT, 3>(a, stats, n_cu, stream, grid, launch);
+    const bool tex = a.scene.mat_maps != nullptr;
+    switch (a.scene.mode) {
+    case PT_MODE_KD: return pt_launch_mode_2(a, waves, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_FLAT_NOMESH: return pt_launch_mode_3(a, waves, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_FLAT_KDMESH: return pt_launch_mode_4(a, waves, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER: return pt_launch_mode_5(a, waves, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, waves, stats, tex, n_cu, stream, grid, launch);
+    default: return pt_launch_mode_1(a, waves, stats, tex, n_cu, stream, grid, launch);
+    }
 }
 
 static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_params* p, PtRenderArgs* a) {
@@ -902,29 +728,42 @@ static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_par
     bool empty = p->slice.x1 < p->slice.x0 || p->slice.y1 < p->slice.y0;  // render.rs:60-65: an inverted slice renders nothing
     a->n_slots = empty ? 0 : pt_slots_per_rank(p);
     a->n_chunks = (p->samples + PT_SAMPLE_CHUNK - 1) / PT_SAMPLE_CHUNK;
-    a->n_work = a->n_slots * a->n_chunks;
+    // K samples of a pixel run side by side in a wavefront: a whole chunk from SAMPLES = 8 on, else the next power of two
+    uint32_t k = PT_SAMPLE_CHUNK;
+    if (p->samples < PT_SAMPLE_CHUNK) { k = 1; while (k < p->samples) k *= 2; }
+    a->lane_samples = k;
+    a->n_items = (a->n_slots / 64) * a->n_chunks * k;
     return PT_OK;
 }
 
 static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStream_t stream) {
+    // LDS per block = traversal stack (as much of it as leaves room for `waves` blocks per CU) + the shaded hit's frame;
+    // deeper stack entries live in HBM (PtStackSpill).
+    const bool tex = a.scene.mat_maps != nullptr;
+    const size_t frame_bytes = (size_t)(tex ? PT_LDS_FRAME_F64_TEX : PT_LDS_FRAME_F64) * PT_BLOCK * 8;
+    const size_t block_budget = c->waves == 4 ? 39 * 1024 : 52 * 1024;  // 4 x 39 KB / 3 x 52 KB of the CU's 160 KB
+    int lds_cap = (int)((block_budget - frame_bytes) / (PT_BLOCK * 4));
+    if (const char* e = getenv("PORTRAYER_LDS_STACK")) lds_cap = std::max(1, atoi(e));  // experiments / tests of the overflow path
+    a.stack_lds_cap = std::min(lds_cap, a.scene.stack_cap);
     uint32_t grid = 0;
     PT_HIP(c, pt_dispatch(a, c->waves, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
-    a.sample_barrier = 1;  // measured +25 % (big-scene, big-soup) to +41 % (mirror): profiles/r01/notes.md step k
-    if (const char* e = getenv("PORTRAYER_SAMPLE_BARRIER")) a.sample_barrier = atoi(e) != 0;
-    a.work_div = std::max<uint32_t>(grid * (PT_BLOCK / 64) * 8u, 1u);  // batch = remaining work / (8 x resident wavefronts)
-    int rc = pt_reserve(c, c->frames, (size_t)a.n_lanes * PT_FRAME_DEPTHS * PT_FRAME_SLOTS * sizeof(double));
-    if (rc) return rc;
+    a.work_div = std::max<uint32_t>(grid * (PT_BLOCK / 64) * 8u, 1u);  // batch = remaining items / (8 x resident wavefronts)
+    int rc;
+    const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_SLOTS * sizeof(double) : 16;
+    if ((rc = pt_reserve(c, c->spill, spill_bytes))) return rc;
+    if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * (size_t)std::max(a.scene.stack_cap - a.stack_lds_cap, 0) * 4))) return rc;
     if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters)))) return rc;
-    if ((rc = pt_reserve(c, c->accum, (size_t)a.n_work * 3 * sizeof(double)))) return rc;
+    if ((rc = pt_reserve(c, c->accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
     a.accum = (double*)c->accum.p;
-    a.frames = (double*)c->frames.p;
+    a.spill = (double*)c->spill.p;
+    a.stack_spill = (uint32_t*)c->stack_spill.p;
     a.work_counter = (unsigned int*)c->misc.p;
     a.overflow_flag = (unsigned int*)c->misc.p + 1;
     a.counters = (PtCounters*)((char*)c->misc.p + 256);
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters), stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
-    if (a.n_work) {
+    if (a.n_items) {
         PT_HIP(c, pt_dispatch(a, c->waves, stats, c->n_cu, stream, &grid, true));
         hipLaunchKernelGGL(pt_finish_kernel, dim3((a.n_slots + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, stream, a);
         PT_HIP(c, hipGetLastError());
@@ -1152,6 +991,7 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     PT_HIP(c, hipMemcpy(d_o, origins, n * 24, hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(d_d, directions, n * 24, hipMemcpyHostToDevice));
     size_t lds = (size_t)c->view.stack_cap * PT_BLOCK * 4;
+    if (lds > 160 * 1024) return pt_fail(c, PT_ERR_SCENE, "pt_test_cast_rays keeps the whole traversal stack in LDS: tree too deep for it");
     dim3 grid((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK));
     auto cast = [&](auto mode) -> hipError_t {
         constexpr int M = decltype(mode)::value;

@@ -12,7 +12,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PT_HD __host__ __device__ __forceinline__
-#define PT_NOINLINE __host__ __device__ __noinline__
+#define PT_NOINLINE static __host__ __device__ __noinline__
 #else
 #define PT_HD inline
 #define PT_NOINLINE inline

@@ -1,0 +1,161 @@
+// The render kernel (render.rs:127-150 and everything below it) and its launcher. Included by
+// pt_render_inst.hip, which is compiled once per traversal mode (six objects built side by side).
+//
+// Kernel design (CDNA4: 64-wide wavefronts, 256 CUs in 8 XCDs, 160 KB LDS per CU, no matrix cores involved -
+// there is no dense contraction on this path):
+//  * persistent wavefronts: the grid is what is resident on the chip. A wavefront takes work ITEMS - 64 / K
+//    neighbouring pixels of an 8x8 tile x K samples of one 8-sample chunk, K = 8 from SAMPLES >= 8 on - from a
+//    private batch it refills with ONE atomicAdd on the launch's counter (guided batch sizes). All 64 lanes
+//    start their samples together and the item ends when the last lane has finished: at any time the
+//    wavefront walks the trees with rays of ONE kind (primary, shadow to light 0, ...) through one 4x2-pixel
+//    window, which is what keeps its lanes in step inside the walk (profiles/r02/notes.md).
+//  * one traversal loop per wavefront for all ray kinds: pt_lane_advance() turns whatever the lane traced
+//    last into its next ray, so secondary rays re-enter the same loop instead of recursing.
+//  * per-lane LDS columns: the traversal stack (32-bit words, overflowing to HBM beyond the LDS part) and
+//    the frame of the hit being shaded (doubles). Recursion frames go to HBM only when a hit spawns a child.
+//  * the chunk's samples are added in ascending order by the lane of the pixel's first sample, reading its
+//    neighbours' finished colours from LDS; pt_finish_kernel adds the chunk sums in order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "pt_shade.h"
+
+#ifndef PT_WORK_BATCH_MAX
+#define PT_WORK_BATCH_MAX 32  // most work items (64 lanes each) a wavefront takes from the global counter at a time
+#endif
+// Waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument) is a
+// template parameter of the render kernel: 3 (168 VGPRs) where shading weighs in, 4 (128 VGPRs, more
+// spills, more latency hiding) where the tree walk dominates - chosen per scene in pt_scene_upload.
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 0  // experiments: force one value for every scene
+#endif
+
+__device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCounters& c) {
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&c);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+    for (unsigned i = 0; i < sizeof(PtCounters) / sizeof(unsigned long long); i++)
+        if (s[i]) atomicAdd(d + i, s[i]);
+}
+
+// LDS of one block: [stack_lds_cap x PT_BLOCK words of traversal stack][frame doubles x PT_BLOCK]
+__host__ __device__ inline size_t pt_render_lds_bytes(int stack_lds_cap, bool tex) {
+    return (size_t)stack_lds_cap * PT_BLOCK * 4 + (size_t)(tex ? PT_LDS_FRAME_F64_TEX : PT_LDS_FRAME_F64) * PT_BLOCK * 8;
+}
+
+template <int MODE, bool STATS, bool TEX, int WAVES>
+__global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES) pt_render_kernel(PtRenderArgs a) {
+    extern __shared__ uint32_t pt_lds[];
+    const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    PtStackSpill stk;
+    stk.base = pt_lds + threadIdx.x;
+    stk.cap = a.stack_lds_cap;
+    stk.total = a.scene.stack_cap;
+    stk.gbase = a.stack_spill + lane_global;
+    stk.gstride = a.n_lanes;
+    stk.overflow = a.overflow_flag;
+    PtFrameRef fr;
+    fr.lds = reinterpret_cast<double*>(pt_lds + (size_t)a.stack_lds_cap * PT_BLOCK) + threadIdx.x;
+    fr.spill = a.spill + lane_global;
+    fr.n_lanes = a.n_lanes;
+
+    PtCounters cnt;
+    if (STATS) memset(&cnt, 0, sizeof cnt);
+    PtLane L;
+    L.stage = PT_ST_DONE; L.has_ray = false; L.ray_any = false;
+    L.x = L.y = L.sample = L.light = L.draw = L.draw0 = L.occluded = 0; L.depth = 0;
+    L.ray.o = L.ray.d = pt_v3(0.0, 0.0, 0.0);
+    PtHit hit;
+    hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
+    unsigned q_next = 0, q_end = 0, q_seen = 0;  // this wavefront's private batch of items (wave-uniform); highest item index seen handed out
+
+    for (;;) {
+        // Next item of the wavefront's private batch; ONE atomicAdd per batch on the launch's counter (a device-scope
+        // atomic round trip stalls the whole wavefront). Guided batch size: large while plenty of work remains, one item
+        // at a time near the end, so the launch's tail stays short.
+        if (q_next == q_end) {
+            unsigned remaining = a.n_items > q_seen ? a.n_items - q_seen : 0u;
+            unsigned take = remaining / a.work_div;
+            take = take > PT_WORK_BATCH_MAX ? PT_WORK_BATCH_MAX : (take < 1u ? 1u : take);
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(a.work_counter, take);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            q_next = base; q_end = base + take; q_seen = q_end;
+        }
+        const unsigned w = q_next++;
+        if (w >= a.n_items) break;
+        PtItemLane it;
+        const bool mine = pt_item_lane(a, w, lane, &it, &L.x, &L.y);
+        L.sample = it.sample;
+        L.stage = mine ? PT_ST_NEW_SAMPLE : PT_ST_DONE;
+        L.has_ray = false;
+        for (;;) {
+            const bool active = L.stage != PT_ST_DONE;
+            if (!__any(active)) break;
+#ifdef PT_DIAG
+            if (STATS) { if (lane == 0) cnt.diag[2]++; if (active) cnt.diag[3]++; }
+#endif
+            if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH>(a, L, hit, fr, &cnt);
+            const bool tracing = L.stage != PT_ST_DONE && L.has_ray;
+#ifdef PT_DIAG
+            if (STATS) {
+                const unsigned long long tm = __ballot(tracing), am = __ballot(tracing && L.ray_any);
+                if (lane == 0) { if (tm) cnt.diag[0]++; if (am) cnt.diag[6]++; }
+                if (tracing) { cnt.diag[1]++; if (L.ray_any) cnt.diag[7]++; }
+            }
+#endif
+            if (tracing) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
+        }
+        // render.rs:36-43 under the summation contract: the chunk's samples in ascending order. A pixel's samples sit
+        // in neighbouring lanes; their colours are in the lanes' LDS columns (same wavefront: program order suffices).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (mine && it.first) {
+            PtVec3 sum = fr.l3(PT_L_VALUE);
+            for (uint32_t k = 1; k < it.count; k++) {
+                const double* o = fr.lds + k;
+                sum = sum + pt_v3(o[(PT_L_VALUE + 0) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 1) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 2) * PT_FRAME_STRIDE]);
+            }
+            double* o = a.accum + 3 * ((size_t)(it.slot >> 6) * a.n_chunks * 64 + (size_t)it.chunk * 64 + (it.slot & 63u));
+            o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (STATS) pt_flush_counters(a.counters, cnt);
+}
+
+// Launch (or, with launch = false, only size) one instantiation. The grid is what is resident: blocks per CU from
+// the occupancy query for this kernel with its LDS.
+template <int MODE, bool STATS, bool TEX, int WAVES>
+static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
+    size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX);
+    static size_t lds_allowed = 64 * 1024;  // per instantiation: raised once, not on every launch
+    hipError_t e;
+    if (lds > lds_allowed) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_allowed = lds;
+    }
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX, WAVES>, PT_BLOCK, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    uint32_t want = (a.n_items + (PT_BLOCK / 64) - 1) / (PT_BLOCK / 64);
+    if (const char* env = getenv("PORTRAYER_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(env)));  // experiment: fewer resident lanes
+    uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
+    *grid_out = grid;
+    if (!launch) return hipSuccess;
+    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int MODE, int WAVES>
+static hipError_t pt_dispatch_variant(const PtRenderArgs& a, bool stats, bool tex, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
+    if (tex) return stats ? pt_launch<MODE, true, true, WAVES>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true, WAVES>(a, n_cu, stream, grid, launch);
+    return stats ? pt_launch<MODE, true, false, WAVES>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false, WAVES>(a, n_cu, stream, grid, launch);
+}

@@ -4,34 +4,39 @@
 // Replaces render_single_pixel (src/render.rs:22-51), Camera::ray_at (src/camera.rs:48-84),
 // Ray::color (src/ray.rs:139-148) and Material::hit_color (src/material.rs:91-320).
 //
-// The reference recurses: hit_color(depth) -> Ray::color(depth + 1) -> hit_color ... and folds the
-// child's colour into the parent AFTER the child returns (`color += reflectivity * child`,
-// material.rs:243,280,307-309,315). A forward "throughput" accumulation would round differently,
-// so each lane keeps an explicit stack of frames (one per depth 0..=10) in HBM and folds them back
-// in recursion order. A lane is a small interpreter: every call to pt_lane_advance() consumes the
-// result of the ray it traced last and runs until it has the NEXT ray to trace (primary, shadow,
-// reflected or refracted) — so all 64 lanes of a wavefront meet again in the traversal loop
-// whatever kind of ray each one carries.
+// A lane owns ONE sample of one pixel at a time (pt_render_kernel maps the 64 lanes of a wavefront to
+// 64 / K neighbouring pixels x K samples of the same pixel). It is a small interpreter: every call to
+// pt_lane_advance() consumes the result of the ray the lane traced last and runs until it has the NEXT
+// ray to trace (primary, shadow, reflected or refracted) - so all 64 lanes of a wavefront meet again in
+// the traversal loop whatever kind of ray each one carries.
 //
-// Frame layout in HBM, structure-of-arrays over lanes so a wavefront's accesses coalesce:
-//   slot s of depth d of lane l at frames[(d * PT_FRAME_SLOTS + s) * n_lanes + l]
-//   slots 0-2 ray direction D (later: reflected colour Cr), 3-5 hit point P (3: Schlick
-//   reflectance once the refracted ray is in flight), 6-8 unit normal N, 9-11 colour so far,
-//   12 {material, frame stage}, 13-15 the texel colour of a textured material (material.rs:138-144).
-// Depth PT_SUM_DEPTH (one past the deepest frame) slots 0-2 hold the pixel's running sample sum.
+// Where the state lives:
+//  * the hit being shaded (its point P, unit normal N, the incoming direction D, material tag, texel
+//    colour) in LDS, one column of doubles per lane next to the traversal stack. It is written once when
+//    the hit is rebuilt and read when its shadow rays come back: nothing of it touches HBM;
+//  * the reference recurses - hit_color(depth) -> Ray::color(depth + 1) -> hit_color ... - and folds the
+//    child's colour into the parent AFTER the child returns (`color += reflectivity * child`,
+//    material.rs:243,280,307-309,315); a forward "throughput" accumulation would round differently. So a
+//    hit that spawns a reflected / refracted child parks what its parent frame still needs in a per-lane
+//    stack in HBM (structure-of-arrays over lanes) and the frames are folded back innermost-first:
+//      slots 0-2 colour so far, 3 {material, frame stage}, 4-6 refracted direction (later: the reflected
+//      colour), 7-9 hit point (origin of the refracted ray), 10 Schlick reflectance.
+//    Hits that spawn nothing (every hit of a scene without reflective materials) never write it.
+//  * a finished sample's colour goes to the lane's LDS column; the lane of the pixel's first sample adds
+//    the chunk's samples in ascending order (the summation contract) and writes the chunk sum.
 #pragma once
 
 #include "pt_trace.h"
 
-#define PT_FRAME_SLOTS 16
 #define PT_MAX_DEPTH 10  // material.rs:12
-#define PT_SUM_DEPTH (PT_MAX_DEPTH + 1)
-#define PT_FRAME_DEPTHS (PT_MAX_DEPTH + 2)
-#define PT_IDLE 0xFFFFFFFFu
+#define PT_SPILL_SLOTS 11
+#define PT_SPILL_DEPTHS (PT_MAX_DEPTH + 1)  // frames at depth 0..9 can have a child in flight; depth 10 only parks a colour between rounds of > 32 lights
+#define PT_LDS_FRAME_F64 10           // P, N, D, tag
+#define PT_LDS_FRAME_F64_TEX 13       // + texel colour
 // Samples of a pixel are summed in chunks of PT_SAMPLE_CHUNK (8): each chunk sequentially (ascending
 // sample index), then the chunk sums sequentially (ascending chunk index). This is the build's
 // summation contract (the reference's rayon reduce has no fixed association, render.rs:36-43); it
-// lets several lanes share one pixel, which keeps all lanes busy when a GPU owns few pixels.
+// lets a chunk's samples run side by side in the lanes of one wavefront.
 #ifndef PT_SAMPLE_CHUNK
 #define PT_SAMPLE_CHUNK 8
 #endif
@@ -44,8 +49,9 @@
 #endif
 
 enum { PT_JITTER_CENTRE = 0, PT_JITTER_RNG = 1 };
-enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_AFTER_LIGHTS = 4 };
-enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_TEXTURED = 256 };
+enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_SHADE = 4, PT_ST_DONE = 5 };
+enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_HAVE_REFRACT = 4, PT_FS_TEXTURED = 256 };
+#define PT_LIGHT_ROUND 32  // shadow-ray results are kept as one bit per light, 32 lights at a time
 
 struct PtRenderArgs {
     PtSceneView scene;
@@ -60,41 +66,47 @@ struct PtRenderArgs {
     uint32_t tile_rank, tile_ranks;  // this launch renders 8x8 tiles t with t % tile_ranks == tile_rank
     uint32_t n_slots;                // pixel slots of this launch (own tiles x 64)
     uint32_t n_chunks;               // sample chunks per pixel: ceil(samples / PT_SAMPLE_CHUNK)
-    uint32_t n_work;                 // work items of this launch = n_slots x n_chunks
-    double* accum;                   // n_work x 3: per (tile, chunk, pixel) sum of the chunk's samples
+    uint32_t lane_samples;           // K = samples that run side by side in a wavefront: 8, or the next power of two >= samples
+    uint32_t n_items;                // wavefront work items of this launch = own tiles x n_chunks x K (each: 64 / K pixels x K samples)
+    double* accum;                   // n_slots x n_chunks x 3: per (tile, chunk, pixel) sum of the chunk's samples
     int32_t compact;                 // 1: rgb is tile-major over own tiles; 0: rgb is the full H x W x 3 image
     uint8_t* rgb;
     double* linear;                  // optional, same indexing as rgb
-    double* frames;
+    double* spill;                   // recursion frames, (depth x PT_SPILL_SLOTS + slot) x n_lanes
     uint32_t n_lanes;
+    uint32_t* stack_spill;           // traversal-stack entries beyond the LDS part, entry x n_lanes
+    int32_t stack_lds_cap;           // entries per lane kept in LDS; the rest (up to scene.stack_cap) in stack_spill
     unsigned int* work_counter;
     unsigned int* overflow_flag;     // set to 1 by any lane that runs out of traversal stack
-    uint32_t work_div;               // a wavefront takes (remaining work / work_div) items from work_counter at a time
-    uint32_t sample_barrier;         // 1: lanes wait at the start of a sample until every lane of the wavefront is there
+    uint32_t work_div;               // a wavefront takes (remaining items / work_div) items from work_counter at a time
     PtCounters* counters;
 };
 
 struct PtLane {
-    uint32_t work;  // slot index in this launch, PT_IDLE when the lane has no pixel
-    uint32_t x, y, sample, sample_end, stage, light, draw;
+    uint32_t x, y, sample, stage, light, draw, draw0, occluded;
     int32_t depth;
     PtRay ray;
     bool has_ray, ray_any;
 };
 
+// This lane's view of its two frame stores.
 struct PtFrameRef {
-    double* base;
+    double* lds;       // column in the block's LDS frame area: slot s at lds[s * PT_FRAME_STRIDE]
+    double* spill;     // column in the HBM recursion stack
     uint32_t n_lanes;
-    PT_HD double& at(int depth, int slot) const { return base[(size_t)(depth * PT_FRAME_SLOTS + slot) * n_lanes]; }
-    PT_HD PtVec3 load3(int depth, int slot) const { return pt_v3(at(depth, slot), at(depth, slot + 1), at(depth, slot + 2)); }
-    PT_HD void store3(int depth, int slot, PtVec3 v) const { at(depth, slot) = v.x; at(depth, slot + 1) = v.y; at(depth, slot + 2) = v.z; }
-    PT_HD void store_tag(int depth, uint32_t mat, uint32_t stage) const {
-        union { double d; uint32_t u[2]; } c; c.u[0] = mat; c.u[1] = stage; at(depth, 12) = c.d;
-    }
-    PT_HD void load_tag(int depth, uint32_t* mat, uint32_t* stage) const {
-        union { double d; uint32_t u[2]; } c; c.d = at(depth, 12); *mat = c.u[0]; *stage = c.u[1];
-    }
+    PT_HD double& l(int slot) const { return lds[slot * PT_FRAME_STRIDE]; }
+    PT_HD PtVec3 l3(int slot) const { return pt_v3(l(slot), l(slot + 1), l(slot + 2)); }
+    PT_HD void set_l3(int slot, PtVec3 v) const { l(slot) = v.x; l(slot + 1) = v.y; l(slot + 2) = v.z; }
+    PT_HD double& h(int depth, int slot) const { return spill[(size_t)(depth * PT_SPILL_SLOTS + slot) * n_lanes]; }
+    PT_HD PtVec3 h3(int depth, int slot) const { return pt_v3(h(depth, slot), h(depth, slot + 1), h(depth, slot + 2)); }
+    PT_HD void set_h3(int depth, int slot, PtVec3 v) const { h(depth, slot) = v.x; h(depth, slot + 1) = v.y; h(depth, slot + 2) = v.z; }
+    static PT_HD double pack_tag(uint32_t mat, uint32_t stage) { union { double d; uint32_t u[2]; } c; c.u[0] = mat; c.u[1] = stage; return c.d; }
+    static PT_HD void unpack_tag(double t, uint32_t* mat, uint32_t* stage) { union { double d; uint32_t u[2]; } c; c.d = t; *mat = c.u[0]; *stage = c.u[1]; }
 };
+// LDS frame slots
+enum { PT_L_P = 0, PT_L_N = 3, PT_L_D = 6, PT_L_TAG = 9, PT_L_KD = 10, PT_L_VALUE = 0 /* a finished sample's colour reuses P */ };
+// HBM spill slots
+enum { PT_H_COLOR = 0, PT_H_TAG = 3, PT_H_DIR = 4, PT_H_P = 7, PT_H_SCHLICK = 10 };
 
 // 8x8 tiles over the slice rectangle, row-major over tiles; pixel slot p = local tile * 64 + j.
 PT_HD bool pt_slot_to_pixel(const PtRenderArgs& a, uint32_t p, uint32_t* x, uint32_t* y) {
@@ -107,12 +119,36 @@ PT_HD bool pt_slot_to_pixel(const PtRenderArgs& a, uint32_t p, uint32_t* x, uint
     *x = px; *y = py;
     return px <= a.x1 && py <= a.y1;
 }
-// Work item w = ((local tile * n_chunks) + chunk) * 64 + j: the 64 lanes of a wavefront start on one
-// 8x8 tile and one sample chunk.
-PT_HD bool pt_work_to_pixel(const PtRenderArgs& a, uint32_t w, uint32_t* x, uint32_t* y, uint32_t* chunk) {
-    uint32_t g = w >> 6;
-    *chunk = g % a.n_chunks;
-    return pt_slot_to_pixel(a, ((g / a.n_chunks) << 6) | (w & 63), x, y);
+// Wavefront work item w = (local tile * n_chunks + chunk) * K + part, K = lane_samples: the wavefront's 64 lanes are
+// 64 / K pixels of the tile (part `part` of it) x K consecutive samples of the chunk, a pixel's samples in
+// neighbouring lanes. Pixels are taken in 4x2-block order - position q of the tile is block q / 8 (two blocks
+// per row of blocks), pixel q % 8 of the block - so that with K = 8 a wavefront's rays all pass through one
+// 4x2-pixel window: they walk the same part of the trees and take about the same number of steps.
+PT_HD uint32_t pt_tile_order_to_slot(uint32_t q) {  // -> j = y * 8 + x inside the 8x8 tile
+    uint32_t b = q >> 3, p = q & 7u;
+    uint32_t x = (b & 1u) * 4u + (p & 3u), y = (b >> 1) * 2u + (p >> 2);
+    return y * 8u + x;
+}
+struct PtItemLane {
+    uint32_t slot;    // pixel slot of this launch (local tile * 64 + j)
+    uint32_t chunk;
+    uint32_t sample;  // absolute sample index
+    uint32_t first;   // 1: this lane holds the first sample of its pixel in this chunk (it sums the chunk)
+    uint32_t count;   // samples of this chunk (<= K)
+};
+PT_HD bool pt_item_lane(const PtRenderArgs& a, uint32_t w, uint32_t lane, PtItemLane* it, uint32_t* x, uint32_t* y) {
+    const uint32_t K = a.lane_samples, per = 64u / K;
+    uint32_t part = w % K, g = w / K;
+    uint32_t chunk = g % a.n_chunks, tile_local = g / a.n_chunks;
+    uint32_t pi = lane / K, si = lane % K;
+    uint32_t j = pt_tile_order_to_slot(part * per + pi);
+    it->slot = (tile_local << 6) | j;
+    it->chunk = chunk;
+    it->sample = chunk * PT_SAMPLE_CHUNK + si;
+    it->first = si == 0u;
+    uint32_t left = a.samples - chunk * PT_SAMPLE_CHUNK;
+    it->count = left < (uint32_t)PT_SAMPLE_CHUNK ? left : (uint32_t)PT_SAMPLE_CHUNK;
+    return pt_slot_to_pixel(a, it->slot, x, y) && si < it->count;
 }
 
 PT_HD PtVec3 pt_background(const PtRenderArgs& a, uint32_t x, uint32_t y) {  // render.rs:31-34
@@ -297,8 +333,8 @@ PT_NOINLINE void pt_apply_maps(const PtTexInfo* tex, const uint8_t* tex_rgb, con
     }
 }
 
-// Runs the lane's interpreter until it needs a ray traced (L.has_ray) or its pixel is finished
-// (L.work == PT_IDLE). `hit` is the result of the ray the lane traced last.
+// Runs the lane's interpreter until it needs a ray traced (L.has_ray) or its sample is finished
+// (L.stage == PT_ST_DONE, colour in the lane's LDS column). `hit` is the result of the ray the lane traced last.
 #ifdef PT_ADVANCE_NOINLINE  // measured slower at every occupancy (profiles/r01/notes.md)
 #define PT_ADVANCE_ATTR PT_NOINLINE
 #else
@@ -315,23 +351,19 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         if (returning) {
             // `value` = Ray::color() of the ray cast at depth L.depth
             returning = false;
-            if (L.depth == 0) {  // render.rs:36-43: the chunk's samples summed in ascending order
-                if (L.sample % PT_SAMPLE_CHUNK != 0) value = fr.load3(PT_SUM_DEPTH, 0) + value;
-                fr.store3(PT_SUM_DEPTH, 0, value);
-                L.sample++;
-                L.stage = PT_ST_NEW_SAMPLE;
-                if (a.sample_barrier) return;  // the wavefront starts its next samples together (pt_render_kernel)
-                continue;
+            if (L.depth == 0) {  // render.rs:36-43: this sample's colour, summed with its chunk by pt_render_kernel
+                fr.set_l3(PT_L_VALUE, value);
+                L.stage = PT_ST_DONE;
+                return;
             }
             L.depth--;
             uint32_t mat, fstage;
-            fr.load_tag(L.depth, &mat, &fstage);
-            const double* m = sc.materials + 10 * (size_t)mat;
-            double reflectivity = m[7], ior = m[9];
-            PtVec3 color = fr.load3(L.depth, 9);
+            PtFrameRef::unpack_tag(fr.h(L.depth, PT_H_TAG), &mat, &fstage);
+            const double reflectivity = sc.materials[10 * (size_t)mat + 7];
+            PtVec3 color = fr.h3(L.depth, PT_H_COLOR);
             if ((fstage & PT_FS_STAGE_MASK) == PT_FS_WAIT_REFRACT) {  // material.rs:305-309
-                PtVec3 reflected = fr.load3(L.depth, 0);
-                double schlick = fr.at(L.depth, 3);
+                PtVec3 reflected = fr.h3(L.depth, PT_H_DIR);
+                double schlick = fr.h(L.depth, PT_H_SCHLICK);
                 double transmittance = 1.0 - schlick;
                 PtVec3 total = reflected * schlick + value * transmittance;
                 value = color + total * reflectivity;
@@ -339,41 +371,17 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 continue;
             }
             // PT_FS_WAIT_REFLECT: `value` is reflected_color (material.rs:242-243)
-            if (!(ior > 0.0)) {  // material.rs:312-316
+            if (!(fstage & PT_FS_HAVE_REFRACT)) {  // opaque (material.rs:312-316) or total internal reflection (:277-284)
                 value = color + value * reflectivity;
                 returning = true;
                 continue;
             }
-            PtVec3 ray_dir = fr.load3(L.depth, 0), P = fr.load3(L.depth, 3), N = fr.load3(L.depth, 6);
-            PtVec3 refract_dir;
-            double cos_incident = 0.0;
-            bool have = false;
-            if (pt_dot(ray_dir, N) < 0.0) {  // entering (material.rs:253-265)
-                if (pt_refracted_direction(ray_dir, N, ior, &refract_dir)) { cos_incident = pt_dot(-ray_dir, N); have = true; }
-            } else if (pt_refracted_direction(ray_dir, -N, 1.0 / ior, &refract_dir)) {  // leaving (:266-276)
-                cos_incident = pt_dot(refract_dir, N); have = true;
-            }
-            if (!have) {  // total internal reflection (:277-284); also where the reference's expect() at :257-258 would panic
-                value = color + value * reflectivity;
-                returning = true;
-                continue;
-            }
-            double r0 = (ior - 1.0) * (ior - 1.0);
-            r0 = r0 / ((ior + 1.0) * (ior + 1.0));
-            double schlick = r0 + (1.0 - r0) * pt_powi5(1.0 - cos_incident);
-            if (L.depth + 1 > PT_MAX_DEPTH) {  // the refracted ray's colour would be discarded (material.rs:102-104): background
-                if (STATS) cnt->depth11_skipped++;
-                PtVec3 bg = pt_background(a, L.x, L.y);
-                double transmittance = 1.0 - schlick;
-                PtVec3 total = value * schlick + bg * transmittance;
-                value = color + total * reflectivity;
-                returning = true;
-                continue;
-            }
-            fr.store3(L.depth, 0, value);
-            fr.at(L.depth, 3) = schlick;
-            fr.store_tag(L.depth, mat, (fstage & PT_FS_TEXTURED) | PT_FS_WAIT_REFRACT);
-            L.ray.o = P; L.ray.d = refract_dir;
+            // the refracted ray (material.rs:286-303); its direction was worked out when the hit was shaded
+            PtVec3 refract_dir = fr.h3(L.depth, PT_H_DIR);
+            L.ray.o = fr.h3(L.depth, PT_H_P);
+            L.ray.d = refract_dir;
+            fr.set_h3(L.depth, PT_H_DIR, value);
+            fr.h(L.depth, PT_H_TAG) = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFRACT);
             L.depth++;
             L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
             if (STATS) cnt->refract++;
@@ -382,13 +390,6 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         switch (L.stage) {
         case PT_ST_NEW_SAMPLE: {
             PT_FENCE;
-            if (L.sample >= L.sample_end) {  // chunk done: hand its sum to the finishing pass
-                PtVec3 sum = fr.load3(PT_SUM_DEPTH, 0);
-                double* o = a.accum + 3 * (size_t)L.work;
-                o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
-                L.work = PT_IDLE;
-                return;
-            }
             double jx = 0.5, jy = 0.5;
             if (a.jitter_mode == PT_JITTER_RNG) {  // render.rs:38-39: x drawn before y
                 uint64_t pixel = (uint64_t)L.y * a.width + L.x;
@@ -439,42 +440,39 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             } else {
                 P = pt_xform_point(sc.fwd + 12 * (size_t)hit.node, p);
             }
-            fr.store3(L.depth, 3, P);
+            fr.set_l3(PT_L_P, P);
             PT_FENCE;
             if (!HIER) Nw = pt_xform_dir(sc.nrm + 9 * (size_t)hit.node, 3, n);
             PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
-            const double* m = sc.materials + 10 * (size_t)mat;
-            PtVec3 kd = pt_v3(m[0], m[1], m[2]);
             uint32_t ftag = 0;
             if (TEX && sc.mat_maps && (sc.mat_maps[2 * mat] >= 0 || sc.mat_maps[2 * mat + 1] >= 0)) {  // material.rs:109-144
-                double kdv[3] = {kd.x, kd.y, kd.z}, nv[3];
+                const double* m = sc.materials + 10 * (size_t)mat;
+                double kdv[3] = {m[0], m[1], m[2]}, nv[3];
                 int has_n;
                 pt_apply_maps(sc.tex, sc.tex_rgb, sc.srgb_lut, sc.uv_trans + 9 * (size_t)mat, sc.tri_v, sc.tri_uv, type, hit.sub,
                               local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z, p.x, p.y, p.z, n.x, n.y, n.z,
                               sc.mat_maps[2 * mat], sc.mat_maps[2 * mat + 1], kdv, nv, &has_n);
-                kd = pt_v3(kdv[0], kdv[1], kdv[2]);
                 if (has_n) N = pt_v3(nv[0], nv[1], nv[2]);
-                fr.store3(L.depth, 13, kd);
+                if (TEX) fr.set_l3(PT_L_KD, pt_v3(kdv[0], kdv[1], kdv[2]));
                 ftag = PT_FS_TEXTURED;
             }
-            fr.store3(L.depth, 6, N);
-            PT_FENCE;
-            PtVec3 color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * kd;  // material.rs:148
-            fr.store3(L.depth, 0, L.ray.d);
-            fr.store3(L.depth, 9, color);
-            fr.store_tag(L.depth, mat, ftag);
+            fr.set_l3(PT_L_N, N);
+            fr.set_l3(PT_L_D, L.ray.d);
+            fr.l(PT_L_TAG) = PtFrameRef::pack_tag(mat, ftag);
             L.light = 0;
+            L.occluded = 0;
+            L.draw0 = L.draw;
             L.stage = PT_ST_LIGHT;
             continue;
         }
-        case PT_ST_LIGHT: {  // material.rs:149-179
+        case PT_ST_LIGHT: {  // material.rs:149-179: one shadow ray per light, whatever the material
             PT_FENCE;
-            if (L.light >= sc.n_lights) { L.stage = PT_ST_AFTER_LIGHTS; continue; }
+            if (L.light >= sc.n_lights) { L.stage = PT_ST_SHADE; continue; }  // a scene without lights
             const double* light = sc.lights + 15 * (size_t)L.light;
             bool is_area;
             PtVec3 lpos = pt_light_position(a, L, light, L.draw, &is_area);
             if (is_area) L.draw += 2;
-            PtVec3 P = fr.load3(L.depth, 3);
+            PtVec3 P = fr.l3(PT_L_P);
             PtVec3 hit_to_light = lpos - P;
             double light_dist = pt_length(hit_to_light);
             L.ray.o = P;
@@ -483,18 +481,31 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             if (STATS) cnt->shadow++;
             return;
         }
-        case PT_ST_SHADOW_DONE: {  // material.rs:179-210
+        case PT_ST_SHADOW_DONE: {  // material.rs:174-179 only asks whether anything is in the way
+            if (hit.node != PT_NO_HIT) L.occluded |= 1u << (L.light % PT_LIGHT_ROUND);
+            L.light++;
+            L.stage = (L.light >= sc.n_lights || L.light % PT_LIGHT_ROUND == 0) ? PT_ST_SHADE : PT_ST_LIGHT;
+            continue;
+        }
+        default: {  // PT_ST_SHADE: material.rs:148-243 for the lights whose shadow rays are back
             PT_FENCE;
-            if (hit.node == PT_NO_HIT) {
-                const double* light = sc.lights + 15 * (size_t)L.light;
+            uint32_t mat, ftag;
+            PtFrameRef::unpack_tag(fr.l(PT_L_TAG), &mat, &ftag);
+            const double* m = sc.materials + 10 * (size_t)mat;
+            PtVec3 ray_dir = fr.l3(PT_L_D), P = fr.l3(PT_L_P), N = fr.l3(PT_L_N);
+            PtVec3 kd = (TEX && (ftag & PT_FS_TEXTURED)) ? fr.l3(PT_L_KD) : pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
+            const uint32_t round_first = (L.light - 1u) / PT_LIGHT_ROUND * PT_LIGHT_ROUND;  // L.light > 0 here unless the scene has no light
+            PtVec3 color;
+            if (sc.n_lights == 0 || round_first == 0) color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * kd;  // material.rs:148
+            else color = fr.h3(L.depth, PT_H_COLOR);  // a later round of a scene with > 32 lights
+            uint32_t draw = L.draw0;
+            for (uint32_t li = sc.n_lights ? round_first : 0u; li < L.light; li++) {  // material.rs:179-210
+                const double* light = sc.lights + 15 * (size_t)li;
                 bool is_area;
-                PtVec3 lpos = pt_light_position(a, L, light, L.draw - 2, &is_area);
+                PtVec3 lpos = pt_light_position(a, L, light, draw, &is_area);
+                if (is_area) draw += 2;
+                if ((L.occluded >> (li - round_first)) & 1u) continue;
                 PtVec3 lcol = pt_v3(light[3], light[4], light[5]);
-                PtVec3 ray_dir = fr.load3(L.depth, 0), P = fr.load3(L.depth, 3), N = fr.load3(L.depth, 6), color = fr.load3(L.depth, 9);
-                uint32_t mat, fstage;
-                fr.load_tag(L.depth, &mat, &fstage);
-                const double* m = sc.materials + 10 * (size_t)mat;
-                PtVec3 kd = (TEX && (fstage & PT_FS_TEXTURED)) ? fr.load3(L.depth, 13) : pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
                 PtVec3 hit_to_light = lpos - P;
                 double light_dist = pt_length(hit_to_light);
                 PtVec3 light_dir = hit_to_light / light_dist;
@@ -509,21 +520,18 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                     specular = (ks * lcol) * nhs;
                 }
                 color = color + (diffuse + specular) / attenuation;
-                fr.store3(L.depth, 9, color);
             }
-            L.light++;
-            L.stage = PT_ST_LIGHT;
-            continue;
-        }
-        default: {  // PT_ST_AFTER_LIGHTS: material.rs:216-243
+            if (L.light < sc.n_lights) {  // more than 32 lights: park the colour and do the next 32
+                fr.set_h3(L.depth, PT_H_COLOR, color);
+                L.occluded = 0;
+                L.draw0 = L.draw;
+                L.stage = PT_ST_LIGHT;
+                continue;
+            }
             PT_FENCE;
-            uint32_t mat, fstage;
-            fr.load_tag(L.depth, &mat, &fstage);
-            const double* m = sc.materials + 10 * (size_t)mat;
-            double reflectivity = m[7], glossy = m[8];
-            PtVec3 color = fr.load3(L.depth, 9);
+            // material.rs:216-243
+            const double reflectivity = m[7], glossy = m[8], ior = m[9];
             if (!(reflectivity > 0.0)) { value = color; returning = true; continue; }
-            PtVec3 ray_dir = fr.load3(L.depth, 0), N = fr.load3(L.depth, 6);
             PtVec3 reflect_dir = ray_dir - (N * 2.0) * pt_dot(ray_dir, N);  // material.rs:218
             if (glossy > 0.0) {  // material.rs:221-239 (not renormalised: quirk Q5)
                 PtVec3 off = (fabs(reflect_dir.x) < PT_EPSILON && fabs(reflect_dir.y) < PT_EPSILON)
@@ -536,15 +544,47 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 L.draw += 2;
                 reflect_dir = reflect_dir + (u_basis * u_coord + v_basis * v_coord);
             }
-            fr.store_tag(L.depth, mat, (fstage & PT_FS_TEXTURED) | PT_FS_WAIT_REFLECT);
-            if (L.depth + 1 > PT_MAX_DEPTH) {  // depth-11 ray: its colour is always the background
+            // The refracted ray (material.rs:245-303) is cast after the reflected subtree has returned; its direction and
+            // the Schlick term depend only on this hit, so they are worked out now and parked with the frame.
+            PtVec3 refract_dir = pt_v3(0.0, 0.0, 0.0);
+            double schlick = 0.0;
+            bool have = false;
+            if (ior > 0.0) {
+                double cos_incident = 0.0;
+                if (pt_dot(ray_dir, N) < 0.0) {  // entering (material.rs:253-265)
+                    if (pt_refracted_direction(ray_dir, N, ior, &refract_dir)) { cos_incident = pt_dot(-ray_dir, N); have = true; }
+                } else if (pt_refracted_direction(ray_dir, -N, 1.0 / ior, &refract_dir)) {  // leaving (:266-276)
+                    cos_incident = pt_dot(refract_dir, N); have = true;
+                }
+                // !have: total internal reflection (:277-284); also where the reference's expect() at :257-258 would panic
+                if (have) {
+                    double r0 = (ior - 1.0) * (ior - 1.0);
+                    r0 = r0 / ((ior + 1.0) * (ior + 1.0));
+                    schlick = r0 + (1.0 - r0) * pt_powi5(1.0 - cos_incident);
+                }
+            }
+            if (L.depth + 1 > PT_MAX_DEPTH) {  // depth-11 rays: their colour is always the background (material.rs:102-104), not traced
                 if (STATS) cnt->depth11_skipped++;
-                L.depth++;
-                value = pt_background(a, L.x, L.y);
+                PtVec3 bg = pt_background(a, L.x, L.y);
+                if (!have) {
+                    value = color + bg * reflectivity;
+                } else {
+                    if (STATS) cnt->depth11_skipped++;
+                    double transmittance = 1.0 - schlick;
+                    PtVec3 total = bg * schlick + bg * transmittance;
+                    value = color + total * reflectivity;
+                }
                 returning = true;
                 continue;
             }
-            L.ray.o = fr.load3(L.depth, 3);
+            fr.set_h3(L.depth, PT_H_COLOR, color);
+            fr.h(L.depth, PT_H_TAG) = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFLECT | (have ? PT_FS_HAVE_REFRACT : 0));
+            if (have) {
+                fr.set_h3(L.depth, PT_H_DIR, refract_dir);
+                fr.set_h3(L.depth, PT_H_P, P);
+                fr.h(L.depth, PT_H_SCHLICK) = schlick;
+            }
+            L.ray.o = P;
             L.ray.d = reflect_dir;
             L.depth++;
             L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;

@@ -19,6 +19,8 @@
 #include "pt_scene_view.h"
 
 #define PT_NO_HIT 0xFFFFFFFFu
+#define PT_BLOCK 256              // threads per block of every traversal kernel = stride of the per-lane LDS columns
+#define PT_FRAME_STRIDE PT_BLOCK
 
 // -DPT_DIAG (profiles/diag.sh): one count per WAVEFRONT pass through a place, next to the per-lane counts the
 // STATS build keeps anyway; their ratio is the lane occupancy of that place.
@@ -36,15 +38,29 @@ struct PtHit {
     uint32_t sub;   // analytic: part tag; mesh / triangle: global triangle index
 };
 
+// Per-lane traversal stack: word i of the lane at base[i * PT_BLOCK] (a column of the block's LDS area: a wave's
+// pushes and pops hit 64 different banks). PtStack is LDS only (pt_cast_kernel); PtStackSpill keeps the first `cap`
+// entries in LDS and the rest - only reached by unusually deep excursions - in HBM, so that the LDS part can be
+// sized for the occupancy instead of for the worst case of the deepest tree.
 struct PtStack {
     uint32_t* base;
-    int stride;
     int cap;
     unsigned int* overflow;  // device word set to 1 when a lane runs out of stack (PT_ERR_TRAVERSAL), in every build
 };
+struct PtStackSpill {
+    uint32_t* base;
+    int cap;                 // entries in LDS
+    int total;               // entries in all
+    uint32_t* gbase;         // entry cap + i of the lane at gbase[i * gstride]
+    uint32_t gstride;
+    unsigned int* overflow;
+};
+PT_HD int pt_stack_total(const PtStack& s) { return s.cap; }
+PT_HD int pt_stack_total(const PtStackSpill& s) { return s.total; }
 // Never expected (pt_scene_upload sizes the stack for the deepest walk); recorded unconditionally so that a render
 // whose results would be wrong cannot return PT_OK.
-PT_HD void pt_stack_overflow(const PtStack& s) {
+template <class Stack>
+PT_HD void pt_stack_overflow(const Stack& s) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (s.overflow) atomicOr(s.overflow, 1u);
 #else
@@ -52,13 +68,23 @@ PT_HD void pt_stack_overflow(const PtStack& s) {
 #endif
 }
 
-PT_HD void pt_push(const PtStack& s, int& sp, uint32_t v) { s.base[sp * s.stride] = v; sp++; }
-PT_HD uint32_t pt_pop(const PtStack& s, int& sp) { sp--; return s.base[sp * s.stride]; }
-PT_HD void pt_push_f64(const PtStack& s, int& sp, double v) {
+PT_HD void pt_push(const PtStack& s, int& sp, uint32_t v) { s.base[sp * PT_BLOCK] = v; sp++; }
+PT_HD uint32_t pt_pop(const PtStack& s, int& sp) { sp--; return s.base[sp * PT_BLOCK]; }
+PT_HD void pt_push(const PtStackSpill& s, int& sp, uint32_t v) {
+    if (sp < s.cap) s.base[sp * PT_BLOCK] = v; else s.gbase[(size_t)(sp - s.cap) * s.gstride] = v;
+    sp++;
+}
+PT_HD uint32_t pt_pop(const PtStackSpill& s, int& sp) {
+    sp--;
+    return sp < s.cap ? s.base[sp * PT_BLOCK] : s.gbase[(size_t)(sp - s.cap) * s.gstride];
+}
+template <class Stack>
+PT_HD void pt_push_f64(const Stack& s, int& sp, double v) {
     union { double d; uint32_t u[2]; } c; c.d = v;
     pt_push(s, sp, c.u[0]); pt_push(s, sp, c.u[1]);
 }
-PT_HD double pt_pop_f64(const PtStack& s, int& sp) {
+template <class Stack>
+PT_HD double pt_pop_f64(const Stack& s, int& sp) {
     union { double d; uint32_t u[2]; } c;
     c.u[1] = pt_pop(s, sp); c.u[0] = pt_pop(s, sp);
     return c.d;
@@ -135,9 +161,9 @@ PT_HD bool pt_slab32_segment(const float* lo, const float* hi, const PtRay32& q,
 // together — the leaf work (f64 primitive tests) is the expensive part and should run with as many
 // lanes active as possible. leaf(first, count, sp) tests the items and returns true to stop the walk
 // (any-hit). `tmax` is re-read after every leaf so shrinking it culls.
-template <bool STATS, class Leaf>
+template <bool STATS, class Stack, class Leaf>
 PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, const double& tmax,
-                       const PtStack& stk, int sp0, Leaf&& leaf, PtCounters* cnt) {
+                       const Stack& stk, int sp0, Leaf&& leaf, PtCounters* cnt) {
     if (root == PT_REF_EMPTY) return false;
     int sp = sp0;
     const PtRay32 q = pt_ray32(r);
@@ -155,7 +181,7 @@ PT_HD bool pt_bvh_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, co
             uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
-                if (sp + 1 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 1 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
                 pt_push(stk, sp, swap ? c0 : c1);
                 cur = swap ? c1 : c0;
             } else if (h0) {
@@ -209,8 +235,8 @@ PT_HD double pt_axis(PtVec3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ?
 // range clipped at straddled planes, the first leaf with a hit wins, and — quirk Q3 — the segment used
 // to classify sides ends at start + extent (squared diagonal), so hits farther away than that can be
 // missed. Reproduced because results differ from Mesh whenever the quirk bites.
-template <bool STATS>
-PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay& local, double start, double end, const PtStack& stk,
+template <bool STATS, class Stack>
+PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay& local, double start, double end, const Stack& stk,
                          int sp0, double* t_out, uint32_t* tri_out, PtCounters* cnt) {
     if (STATS) cnt->n_bbox++;
     if (!pt_bbox_test_hit(m.kd_bbox_inv, local, start, end)) return false;
@@ -252,7 +278,7 @@ PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay
             if (s == e) { cur = s ? n.front : n.back; continue; }
             double plane_t = (n.plane - o) / d;
             if (pt_in_range(start, end, plane_t)) {
-                if (sp + 3 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 3 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
                 pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));  // pending far side: (node, start = plane_t)
                 pt_push_f64(stk, sp, plane_t);
                 cur = s ? n.front : n.back;
@@ -271,9 +297,9 @@ PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay
 
 // flat_scene.rs:71-99 for one flattened node: transform the ray into model space, dispatch on the
 // primitive (primitive.rs:55-62), keep the hit if it beats `best`. Returns true if best changed.
-template <bool STATS, bool MESH = true>
+template <bool STATS, bool MESH = true, class Stack = PtStack>
 PT_HD bool pt_test_node(const PtSceneView& sc, uint32_t node, const PtRay& ray, double start, PtHit& best, bool any,
-                        const PtStack& stk, int sp, PtCounters* cnt) {
+                        const Stack& stk, int sp, PtCounters* cnt) {
     const uint32_t* info = sc.info + 4 * (size_t)node;
     uint32_t type = info[0], data = info[1];
     PtRay local = pt_ray_to_local(sc.inv + 12 * (size_t)node, ray);
@@ -330,8 +356,8 @@ PT_HD bool pt_test_node(const PtSceneView& sc, uint32_t node, const PtRay& ray, 
 // FLAT mode for scenes WITHOUT mesh instances: the generic walk with a one-node leaf handler.
 // (Measured 4 % faster on big-scene than the two-level loop below with its mesh path compiled out:
 // fewer loop-carried registers.)
-template <bool STATS>
-PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
+template <bool STATS, class Stack>
+PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
     best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
     if (sc.n_nodes == 0) return false;
     pt_bvh_walk<STATS>(sc.bvh, sc.tlas_root, ray, best.t, stk, 0,
@@ -357,8 +383,8 @@ PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool an
 #define PT_REF_MARKER 0xFFFFFFFEu
 // MESH = false compiles the mesh-instance path out (scenes of analytic primitives and stand-alone
 // triangles only): fewer live registers in the hot loop.
-template <bool STATS, bool MESH, bool KDMESH = MESH, bool HIER = false>
-PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
+template <bool STATS, bool MESH, bool KDMESH = MESH, bool HIER = false, class Stack = PtStack>
+PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
     best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
     if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return false;
     int sp = 0;
@@ -378,7 +404,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
             uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
-                if (sp + 1 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
+                if (sp + 1 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
                 pt_push(stk, sp, swap ? c0 : c1);
                 cur = swap ? c1 : c0;
             } else if (h0) {
@@ -420,7 +446,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                     const PtMeshInfo& m = sc.meshes[data];
                     if (STATS) cnt->n_bbox++;
                     if (m.blas_root == PT_REF_EMPTY || !pt_bbox_test_hit(m.bbox_inv, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, item, 0))) continue;
-                    if (sp + 2 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
+                    if (sp + 2 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
                     // remaining items of this leaf (scene leaves hold one node unless PORTRAYER_TLAS_LEAF > 1)
                     if (i + 1 < count) pt_push(stk, sp, PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2));
                     pt_push(stk, sp, PT_REF_MARKER);
@@ -458,8 +484,8 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
 // KD mode: kdtree/node.rs:112-202. A pending far side is (node, start) = 3 words: its range end is
 // the start of the entry below it on the stack (or +inf), because the current `end` always equals
 // the plane parameter of the innermost straddled split whose near side is being walked.
-template <bool STATS>
-PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const PtStack& stk, PtCounters* cnt) {
+template <bool STATS, class Stack>
+PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
     best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
     double start = PT_EPSILON, end = INFINITY;  // ray.rs:140
     int sp = 0;
@@ -507,7 +533,7 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
             if (s == e) { cur = s ? n.front : n.back; continue; }
             double plane_t = (n.plane - o) / d;                              // node.rs:90-109
             if (pt_in_range(start, end, plane_t)) {
-                if (sp + 3 > stk.cap) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 3 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
                 pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));
                 pt_push_f64(stk, sp, plane_t);
                 cur = s ? n.front : n.back;
@@ -523,4 +549,15 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
         if (sp == 0) end = INFINITY;
         else { int peek = sp; end = pt_pop_f64(stk, peek); }
     }
+}
+
+// Traversal of one ray in the semantics of `MODE` (PT_MODE_*).
+template <int MODE, bool STATS, class Stack>
+PT_HD void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const Stack& stk, PtCounters* cnt) {
+    if (MODE == PT_MODE_KD) pt_trace_kd<STATS>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_HIER) pt_trace_flat<STATS, true, true, true>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_HIER_NOMESH) pt_trace_flat<STATS, false, false, true>(sc, ray, any, hit, stk, cnt);
+    else pt_trace_flat<STATS, true, false>(sc, ray, any, hit, stk, cnt);
 }
