@@ -28,7 +28,7 @@ examples/bin/%: examples/%.cpp portrayer_amd/libportrayer_host.so
 OBJDIR ?= $(CSRC)
 HIPLIB ?= portrayer_amd/libportrayer_hip.so
 RENDER_MODES := 1 2 3 4 5 6
-HIP_OBJS := $(OBJDIR)/pt_api.o $(OBJDIR)/pt_build.o $(foreach m,$(RENDER_MODES),$(OBJDIR)/pt_render_m$(m).o)
+HIP_OBJS := $(OBJDIR)/pt_api.o $(OBJDIR)/pt_build.o $(OBJDIR)/pt_node.o $(foreach m,$(RENDER_MODES),$(OBJDIR)/pt_render_m$(m).o)
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	@mkdir -p $(OBJDIR)
@@ -39,7 +39,7 @@ $(OBJDIR)/pt_render_m%.o: $(CSRC)/pt_render_inst.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DPT_INST_MODE=$* -c $< -o $@
 
 $(HIPLIB): $(HIP_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared $^ -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared $^ -o $@ -ldl
 
 # the device objects alone (`make -B hipobjs` = the forced recompile of __graft_entry__.build())
 hipobjs: $(HIP_OBJS)

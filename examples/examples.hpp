@@ -25,6 +25,8 @@ Example primitives_simple();                                     // examples/pri
 Example macho_cows(const std::string& assets_dir);               // examples/macho-cows.rs
 Example entering_the_mirror_dimension(const std::string& assets_dir);  // examples/entering-the-mirror-dimension.rs
 Example big_scene(int n = 10);                                   // examples/big-scene.rs (n = objects per axis)
+Example synthetic_big_mesh(const std::string& assets_dir, int n = 6);  // the big-scene generator over Mesh(cow.obj) instances (not a reference scene)
+Example synthetic_big_soup(const std::string& assets_dir, int n = 6);  // the same instances baked to one 1.25 M-triangle mesh
 Example smooth_shading(const std::string& assets_dir);           // examples/smooth-shading.rs
 Example glossy_reflection();                                     // examples/glossy-reflection.rs
 Example soft_shadows(const std::string& assets_dir);             // examples/soft-shadows.rs

@@ -220,6 +220,25 @@ int pt_tile_slot_pixel(const pt_render_params *params, uint32_t rank, uint32_t s
 /* Host version of pt_untile_device: gathered = tile_ranks x pt_compact_bytes(), rank-major. */
 int pt_untile_host(const pt_render_params *params, const uint8_t *gathered, uint8_t *rgb);
 
+/* ---- One render call over the GPUs of a node (ABI 5). One context per GPU, the scene replicated; the slice's 8x8
+ * tiles are dealt round-robin to the ranks, each rank renders its tiles into a compact buffer on its own stream, ONE
+ * RCCL gather (ncclGather over xGMI, single process) brings them to rank 0, which untiles them. The slice API of the
+ * reference (src/render.rs:56-66, :211-213) is the rectangular special case this generalises. `devices` = n_devices
+ * device indices (NULL: 0 .. n_devices - 1); ranks may share a device (then the gather is device-to-device copies:
+ * RCCL needs distinct GPUs). RCCL is loaded on first use. */
+typedef struct pt_node pt_node;
+int pt_node_create(int n_devices, const int *devices, pt_node **out);
+void pt_node_destroy(pt_node *node);
+const char *pt_node_last_error(const pt_node *node);
+int pt_node_ranks(const pt_node *node);
+int pt_node_uses_rccl(const pt_node *node);          /* 1: the gather is RCCL; 0: ranks share a device, copies */
+pt_context *pt_node_context(pt_node *node, int rank);
+int pt_node_scene_upload(pt_node *node, const pt_scene *scene, int traverse, const pt_kdtree *kd);
+/* Like pt_render (host buffers; params->tile_rank / tile_ranks must be 0 / 1: the node partitions the tiles itself).
+ * stats: counters summed over the ranks, kernel_ms of the slowest rank, total_ms of the whole call. */
+int pt_node_render(pt_node *node, const pt_camera *camera, const double *background, const pt_render_params *params,
+                   uint8_t *rgb, pt_stats *stats);
+
 /* Device-side helpers used by the measurement harness. */
 int pt_device_alloc(pt_context *ctx, uint64_t bytes, void **out);
 int pt_device_free(pt_context *ctx, void *ptr);

@@ -92,6 +92,11 @@ int ph_obj_load(const char *path, uint64_t counts[3], double *positions, double 
 int ph_renderer_create(const ph_scene *scene, int traverse, int kd_depth, int device, ph_renderer **out);
 void ph_renderer_destroy(ph_renderer *r);
 pt_context *ph_renderer_context(ph_renderer *r);
+/* 1, or the number of ranks when PORTRAYER_GPUS / PORTRAYER_DEVICES put the scene on a node (pt_node_*) */
+int ph_renderer_ranks(ph_renderer *r);
+/* where the time before the first pixel went, in ms: flatten (flat_scene.rs:18-46), packing the ABI arrays, context / node
+ * creation, the reference's k-d tree build (kdtree feature only), pt_scene_upload (device trees included) */
+int ph_renderer_prepare_ms(ph_renderer *r, double out[5]);
 /* The pixel loop (render.rs:127-150) on the GPU, host buffers in and out (see pt_render). */
 int ph_renderer_render(ph_renderer *r, const double camera[10], const pt_render_params *params, const double *background,
                        uint8_t *rgb, double *linear, pt_stats *stats);

@@ -10,6 +10,7 @@
 #include "po_math.h"
 
 #include <pthread.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <unistd.h>
@@ -1015,14 +1016,23 @@ static void *render_worker(void *arg) {
     return NULL;
 }
 
+/* Wall time of the last po_render call, split where render.rs splits it: scene conversion (render.rs:115-126: flatten,
+ * k-d tree builds) and the pixel loop (render.rs:127-150). For bench.py's CPU baseline, which times the pixel loop. */
+static double g_last_prepare_ms = 0.0, g_last_pixels_ms = 0.0;
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+void po_last_render_ms(double out[2]) { out[0] = g_last_prepare_ms; out[1] = g_last_pixels_ms; }
+
 int po_render(const po_scene *scene, const po_camera_settings *cam, const double *background,
               const po_render_params *p, uint8_t *rgb, double *linear, po_stats *stats) {
     if (!scene || !cam || !background || !p || !rgb) return -1;
     if (p->x0 >= p->width || p->y0 >= p->height || p->x1 >= p->width || p->y1 >= p->height) return -5; /* render.rs:79-90 panics */
     if (p->samples == 0) return -6;
     ctx_t cx;
+    double t_begin = now_ms();
     int rc = ctx_init(&cx, scene, p->mode, p->kd_depth, p->kd_mesh_depth);
     if (rc) { ctx_free(&cx); return rc; }
+    double t_loop = now_ms();
+    g_last_prepare_ms = t_loop - t_begin;
     camera_t c = camera_new(cam, (double)p->width, (double)p->height);
     job_t j; memset(&j, 0, sizeof j);
     j.cx = &cx; j.cam = &c; j.bg = background; j.p = p; j.rgb = rgb; j.linear = linear; j.next_row = p->y0;
@@ -1039,6 +1049,7 @@ int po_render(const po_scene *scene, const po_camera_settings *cam, const double
         free(th);
     }
     pthread_mutex_destroy(&j.lock);
+    g_last_pixels_ms = now_ms() - t_loop;
     if (stats) *stats = j.total;
     ctx_free(&cx);
     return 0;

@@ -103,6 +103,9 @@ typedef struct {
 int po_render(const po_scene *scene, const po_camera_settings *cam, const double *background,
               const po_render_params *params, uint8_t *rgb, double *linear, po_stats *stats);
 
+/* out[0] = ms the last po_render spent converting the scene (render.rs:115-126), out[1] = ms in its pixel loop (render.rs:127-150) */
+void po_last_render_ms(double out[2]);
+
 /* Casts explicit world-space rays through the scene in the given mode (ray.rs:139-148 minus
  * shading): out_t = ray parameter or +inf, out_id = flat node index (BFS order) or -1. In HIER
  * mode out_id is -1/0 only. */

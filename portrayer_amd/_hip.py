@@ -88,7 +88,8 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = ["pt_abi_version", "pt_device_count", "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_scene_upload",
            "pt_render", "pt_render_device", "pt_render_finish", "pt_compact_bytes", "pt_untile_device", "pt_tile_slot_pixel", "pt_untile_host", "pt_device_alloc",
            "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_synchronize", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
-           "pt_test_math"]
+           "pt_test_math", "pt_node_create", "pt_node_destroy", "pt_node_last_error", "pt_node_ranks", "pt_node_uses_rccl", "pt_node_context",
+           "pt_node_scene_upload", "pt_node_render"]
 
 
 def header_functions():
@@ -151,6 +152,22 @@ def lib() -> C.CDLL:
         l.pt_test_cast_rays.argtypes = [C.c_void_p, C.c_uint64, _dp, _dp, C.c_int, _dp, _ip, _ip]
         l.pt_test_math.restype = C.c_int
         l.pt_test_math.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _dp, _dp, _dp]
+        l.pt_node_create.restype = C.c_int
+        l.pt_node_create.argtypes = [C.c_int, _ip, C.POINTER(C.c_void_p)]
+        l.pt_node_destroy.restype = None
+        l.pt_node_destroy.argtypes = [C.c_void_p]
+        l.pt_node_last_error.restype = C.c_char_p
+        l.pt_node_last_error.argtypes = [C.c_void_p]
+        l.pt_node_ranks.restype = C.c_int
+        l.pt_node_ranks.argtypes = [C.c_void_p]
+        l.pt_node_uses_rccl.restype = C.c_int
+        l.pt_node_uses_rccl.argtypes = [C.c_void_p]
+        l.pt_node_context.restype = C.c_void_p
+        l.pt_node_context.argtypes = [C.c_void_p, C.c_int]
+        l.pt_node_scene_upload.restype = C.c_int
+        l.pt_node_scene_upload.argtypes = [C.c_void_p, C.POINTER(PtScene), C.c_int, C.POINTER(PtKdTree)]
+        l.pt_node_render.restype = C.c_int
+        l.pt_node_render.argtypes = [C.c_void_p, C.POINTER(PtCamera), _dp, C.POINTER(PtRenderParams), _u8p, C.POINTER(PtStats)]
         _lib = l
     return _lib
 

@@ -50,6 +50,8 @@ __global__ void pt_math_kernel(int op, uint64_t n, const double* a, const double
     case 1: r = a[i] / b[i]; break;
     case 2: r = pow(a[i], b[i]); break;
     case 3: r = a[i] * b[i] + a[i]; break;  // must NOT be fused (-ffp-contract=off)
+    case 4: r = atan2(a[i], b[i]); break;   // sphere.rs:57-58 (texture coordinates)
+    case 5: r = acos(a[i]); break;          // sphere.rs:59
     default: r = 0.0; break;
     }
     out[i] = r;
@@ -643,17 +645,12 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
         v.chain_off = (const uint32_t*)c->chain_off.p; v.chain = (const uint32_t*)c->chain.p; v.dfs_rank = (const uint32_t*)c->dfs_rank.p;
     }
-    // mesh-heavy scenes spend > 90 % of the wave cycles in the tree walk and gain from a 4th wave (big-soup 2.46 -> 2.75 Gray/s);
-    // scenes with a few small meshes lose (mirror 11.8 -> 10.7, cows 8.9 -> 7.8)
-    // and so does the reference's k-d tree on small scenes (mirror KD 3.8 -> 3.6) but not on big-scene (1.40 -> 1.65).
-    {
-        double instanced = 0.0;  // primitives a ray can meet, mesh instances counted with their triangles
-        for (uint32_t i = 0; i < n; i++) {
-            int32_t t = s->prim_type[i];
-            instanced += (t == PT_PRIM_MESH || t == PT_PRIM_KDMESH) ? (double)(s->mesh_tri_off[s->prim_data[i] + 1] - s->mesh_tri_off[s->prim_data[i]]) : 1.0;
-        }
-        c->waves = traverse == PT_TRAVERSE_KD ? (n >= 256 ? 4 : 3) : (instanced >= 262144.0 ? 4 : 3);
-    }
+    // Waves per SIMD the launch is compiled for: 3 (168 VGPRs). Round 1 picked 4 (128 VGPRs, more spills, more latency
+    // hiding) for mesh-heavy scenes and large k-d trees; with a wavefront's rays confined to one 4x2-pixel window the walk
+    // waits less and the spills of the 128-register build cost more than the fourth wave hides (profiles/r02/notes.md:
+    // big-soup 3.24 vs 3.13 Gray/s, big-mesh 3.69 vs 3.67, cows 12.0 vs 10.7, mirror 14.5 vs 13.2, big-scene KD 7.2 vs 7.1).
+    // The 4-wave instantiations stay selectable (PORTRAYER_WAVES=4) and tested.
+    c->waves = 3;
     if (const char* e = getenv("PORTRAYER_WAVES")) c->waves = atoi(e) == 4 ? 4 : 3;
     int below = std::max(max_blas_depth, 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
     int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + below + 2 : tlas.depth + below + 4;
@@ -739,6 +736,7 @@ static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_par
 static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStream_t stream) {
     // LDS per block = traversal stack (as much of it as leaves room for `waves` blocks per CU) + the shaded hit's frame;
     // deeper stack entries live in HBM (PtStackSpill).
+    if (getenv("PORTRAYER_NO_TEX")) a.scene.mat_maps = nullptr;  // experiment: the untextured kernel on a textured scene (wrong picture, timing only)
     const bool tex = a.scene.mat_maps != nullptr;
     const size_t frame_bytes = (size_t)(tex ? PT_LDS_FRAME_F64_TEX : PT_LDS_FRAME_F64) * PT_BLOCK * 8;
     const size_t block_budget = c->waves == 4 ? 39 * 1024 : 52 * 1024;  // 4 x 39 KB / 3 x 52 KB of the CU's 160 KB
@@ -750,7 +748,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.n_lanes = grid * PT_BLOCK;
     a.work_div = std::max<uint32_t>(grid * (PT_BLOCK / 64) * 8u, 1u);  // batch = remaining items / (8 x resident wavefronts)
     int rc;
-    const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_SLOTS * sizeof(double) : 16;
+    const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_STRIDE * sizeof(double) : 16;
     if ((rc = pt_reserve(c, c->spill, spill_bytes))) return rc;
     if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * (size_t)std::max(a.scene.stack_cap - a.stack_lds_cap, 0) * 4))) return rc;
     if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters)))) return rc;
@@ -956,9 +954,10 @@ extern "C" int pt_measure_copy_bandwidth(pt_context* c, uint64_t bytes, int iter
     PT_HIP(c, hipMemset(src, 1, bytes));
     size_t n = bytes / 16;
     double best = 0.0;
-    for (int i = 0; i < iters + 1; i++) {
+    const int per_cu[4] = {8, 16, 32, 64};  // resident copy blocks per CU: the best of a few grid sizes is the box's roofline
+    for (int i = 0; i < 4 * iters + 1; i++) {
         PT_HIP(c, hipEventRecord(c->ev0, nullptr));
-        hipLaunchKernelGGL(pt_copy_kernel, dim3(c->n_cu * 8), dim3(256), 0, nullptr, (const double2*)src, (double2*)dst, n);
+        hipLaunchKernelGGL(pt_copy_kernel, dim3(c->n_cu * per_cu[i % 4]), dim3(256), 0, nullptr, (const double2*)src, (double2*)dst, n);
         PT_HIP(c, hipEventRecord(c->ev1, nullptr));
         PT_HIP(c, hipEventSynchronize(c->ev1));
         float ms = 0.f;

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
     stk.overflow = a.overflow_flag;
     PtFrameRef fr;
     fr.lds = reinterpret_cast<double*>(pt_lds + (size_t)a.stack_lds_cap * PT_BLOCK) + threadIdx.x;
-    fr.spill = a.spill + lane_global;
+    fr.spill = a.spill + (size_t)lane_global * (PT_SPILL_DEPTHS * PT_SPILL_STRIDE);
     fr.n_lanes = a.n_lanes;
 
     PtCounters cnt;

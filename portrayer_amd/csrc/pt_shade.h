@@ -18,9 +18,12 @@
 //    child's colour into the parent AFTER the child returns (`color += reflectivity * child`,
 //    material.rs:243,280,307-309,315); a forward "throughput" accumulation would round differently. So a
 //    hit that spawns a reflected / refracted child parks what its parent frame still needs in a per-lane
-//    stack in HBM (structure-of-arrays over lanes) and the frames are folded back innermost-first:
+//    stack in HBM and the frames are folded back innermost-first. A parked frame is one 128-byte line of its
+//    lane's own region (lanes of a wavefront push and pop at different times and depths once their paths have
+//    diverged: a structure-of-arrays layout over lanes cost one line per SLOT then - measured on the
+//    transmission-refraction scene, profiles/r02/notes.md):
 //      slots 0-2 colour so far, 3 {material, frame stage}, 4-6 refracted direction (later: the reflected
-//      colour), 7-9 hit point (origin of the refracted ray), 10 Schlick reflectance.
+//      colour), 7-9 hit point (origin of the refracted ray), 10 Schlick reflectance, 11 reflectivity.
 //    Hits that spawn nothing (every hit of a scene without reflective materials) never write it.
 //  * a finished sample's colour goes to the lane's LDS column; the lane of the pixel's first sample adds
 //    the chunk's samples in ascending order (the summation contract) and writes the chunk sum.
@@ -30,6 +33,7 @@
 
 #define PT_MAX_DEPTH 10  // material.rs:12
 #define PT_SPILL_SLOTS 11
+#define PT_SPILL_STRIDE 16  // doubles per parked frame: one 128-byte line, so that a push or pop of one lane touches one line
 #define PT_SPILL_DEPTHS (PT_MAX_DEPTH + 1)  // frames at depth 0..9 can have a child in flight; depth 10 only parks a colour between rounds of > 32 lights
 #define PT_LDS_FRAME_F64 10           // P, N, D, tag
 #define PT_LDS_FRAME_F64_TEX 13       // + texel colour
@@ -72,7 +76,7 @@ struct PtRenderArgs {
     int32_t compact;                 // 1: rgb is tile-major over own tiles; 0: rgb is the full H x W x 3 image
     uint8_t* rgb;
     double* linear;                  // optional, same indexing as rgb
-    double* spill;                   // recursion frames, (depth x PT_SPILL_SLOTS + slot) x n_lanes
+    double* spill;                   // recursion frames, lane x PT_SPILL_DEPTHS x PT_SPILL_STRIDE
     uint32_t n_lanes;
     uint32_t* stack_spill;           // traversal-stack entries beyond the LDS part, entry x n_lanes
     int32_t stack_lds_cap;           // entries per lane kept in LDS; the rest (up to scene.stack_cap) in stack_spill
@@ -97,7 +101,7 @@ struct PtFrameRef {
     PT_HD double& l(int slot) const { return lds[slot * PT_FRAME_STRIDE]; }
     PT_HD PtVec3 l3(int slot) const { return pt_v3(l(slot), l(slot + 1), l(slot + 2)); }
     PT_HD void set_l3(int slot, PtVec3 v) const { l(slot) = v.x; l(slot + 1) = v.y; l(slot + 2) = v.z; }
-    PT_HD double& h(int depth, int slot) const { return spill[(size_t)(depth * PT_SPILL_SLOTS + slot) * n_lanes]; }
+    PT_HD double& h(int depth, int slot) const { return spill[depth * PT_SPILL_STRIDE + slot]; }
     PT_HD PtVec3 h3(int depth, int slot) const { return pt_v3(h(depth, slot), h(depth, slot + 1), h(depth, slot + 2)); }
     PT_HD void set_h3(int depth, int slot, PtVec3 v) const { h(depth, slot) = v.x; h(depth, slot + 1) = v.y; h(depth, slot + 2) = v.z; }
     static PT_HD double pack_tag(uint32_t mat, uint32_t stage) { union { double d; uint32_t u[2]; } c; c.u[0] = mat; c.u[1] = stage; return c.d; }
@@ -106,7 +110,7 @@ struct PtFrameRef {
 // LDS frame slots
 enum { PT_L_P = 0, PT_L_N = 3, PT_L_D = 6, PT_L_TAG = 9, PT_L_KD = 10, PT_L_VALUE = 0 /* a finished sample's colour reuses P */ };
 // HBM spill slots
-enum { PT_H_COLOR = 0, PT_H_TAG = 3, PT_H_DIR = 4, PT_H_P = 7, PT_H_SCHLICK = 10 };
+enum { PT_H_COLOR = 0, PT_H_TAG = 3, PT_H_DIR = 4, PT_H_P = 7, PT_H_SCHLICK = 10, PT_H_REFL = 11 /* the material's reflectivity: the pop needs no material fetch */ };
 
 // 8x8 tiles over the slice rectangle, row-major over tiles; pixel slot p = local tile * 64 + j.
 PT_HD bool pt_slot_to_pixel(const PtRenderArgs& a, uint32_t p, uint32_t* x, uint32_t* y) {
@@ -359,7 +363,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             L.depth--;
             uint32_t mat, fstage;
             PtFrameRef::unpack_tag(fr.h(L.depth, PT_H_TAG), &mat, &fstage);
-            const double reflectivity = sc.materials[10 * (size_t)mat + 7];
+            const double reflectivity = fr.h(L.depth, PT_H_REFL);
             PtVec3 color = fr.h3(L.depth, PT_H_COLOR);
             if ((fstage & PT_FS_STAGE_MASK) == PT_FS_WAIT_REFRACT) {  // material.rs:305-309
                 PtVec3 reflected = fr.h3(L.depth, PT_H_DIR);
@@ -579,6 +583,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             }
             fr.set_h3(L.depth, PT_H_COLOR, color);
             fr.h(L.depth, PT_H_TAG) = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFLECT | (have ? PT_FS_HAVE_REFRACT : 0));
+            fr.h(L.depth, PT_H_REFL) = reflectivity;
             if (have) {
                 fr.set_h3(L.depth, PT_H_DIR, refract_dir);
                 fr.set_h3(L.depth, PT_H_P, P);

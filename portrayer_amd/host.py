@@ -19,7 +19,7 @@ _dp, _ip, _up, _u64p, _u8p = H._dp, H._ip, H._up, H._u64p, H._u8p
 
 EXPORTS = ["ph_last_error", "ph_scene_create", "ph_example_scene", "ph_scene_destroy", "ph_scene_counts", "ph_scene_export",
            "ph_scene_flatten", "ph_scene_kdtree", "ph_camera", "ph_obj_load", "ph_renderer_create", "ph_renderer_destroy",
-           "ph_renderer_context", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write", "ph_image_read", "ph_scene_graph"]
+           "ph_renderer_context", "ph_renderer_ranks", "ph_renderer_prepare_ms", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write", "ph_image_read", "ph_scene_graph"]
 
 
 class PortrayerHostError(RuntimeError):
@@ -71,6 +71,8 @@ def lib() -> C.CDLL:
         l.ph_renderer_create.restype = C.c_int; l.ph_renderer_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         l.ph_renderer_destroy.restype = None; l.ph_renderer_destroy.argtypes = [vp]
         l.ph_renderer_context.restype = vp; l.ph_renderer_context.argtypes = [vp]
+        l.ph_renderer_ranks.restype = C.c_int; l.ph_renderer_ranks.argtypes = [vp]
+        l.ph_renderer_prepare_ms.restype = C.c_int; l.ph_renderer_prepare_ms.argtypes = [vp, _dp]
         l.ph_renderer_render.restype = C.c_int
         l.ph_renderer_render.argtypes = [vp, _dp, C.POINTER(H.PtRenderParams), _dp, _u8p, _dp, C.POINTER(H.PtStats)]
         l.ph_example_render_to_png.restype = C.c_int
@@ -239,6 +241,15 @@ class Renderer:
     @property
     def context(self):
         return lib().ph_renderer_context(self._h)
+
+    @property
+    def ranks(self) -> int:
+        return int(lib().ph_renderer_ranks(self._h))
+
+    def prepare_ms(self) -> dict:
+        out = np.zeros(5)
+        _check(lib().ph_renderer_prepare_ms(self._h, _p(out, _dp)), "ph_renderer_prepare_ms")
+        return dict(zip(("flatten", "pack_arrays", "context", "kd_build", "upload_and_device_trees"), map(float, out)))
 
     def render(self, cam10, width: int, height: int, background: np.ndarray, samples: int = 1, seed: int = 0,
                sample_mode: int = H.SAMPLE_CENTRE, rect=None, stats: bool = False, into: Optional[np.ndarray] = None, want_linear: bool = True):

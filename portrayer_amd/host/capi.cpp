@@ -160,6 +160,8 @@ static examples::Example make_example(const std::string& name, const std::string
     if (name == "macho-cows") return examples::macho_cows(assets);
     if (name == "entering-the-mirror-dimension") return examples::entering_the_mirror_dimension(assets);
     if (name == "big-scene") return examples::big_scene(n > 1 ? n : 10);
+    if (name == "synthetic:big-mesh") return examples::synthetic_big_mesh(assets, n > 1 ? n : 6);
+    if (name == "synthetic:big-soup") return examples::synthetic_big_soup(assets, n > 1 ? n : 6);
     if (name == "smooth-shading") return examples::smooth_shading(assets);
     if (name == "glossy-reflection") return examples::glossy_reflection();
     if (name == "soft-shadows") return examples::soft_shadows(assets);
@@ -426,6 +428,13 @@ extern "C" int ph_renderer_create(const ph_scene* s, int traverse, int kd_depth,
 }
 extern "C" void ph_renderer_destroy(ph_renderer* r) { delete r; }
 extern "C" pt_context* ph_renderer_context(ph_renderer* r) { return r ? r->r->context() : nullptr; }
+extern "C" int ph_renderer_ranks(ph_renderer* r) { return !r ? 0 : (r->r->node() ? pt_node_ranks(r->r->node()) : 1); }
+extern "C" int ph_renderer_prepare_ms(ph_renderer* r, double out[5]) {
+    if (!r || !out) return bad("null argument");
+    const auto& p = r->r->prepare_ms();
+    out[0] = p.flatten; out[1] = p.pack; out[2] = p.context; out[3] = p.kd_build; out[4] = p.upload;
+    return PH_OK;
+}
 
 extern "C" int ph_renderer_render(ph_renderer* r, const double camera[10], const pt_render_params* p, const double* background,
                                   uint8_t* rgb, double* linear, pt_stats* stats) {

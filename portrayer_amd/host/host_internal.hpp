@@ -84,12 +84,17 @@ class Renderer {
     void render(const camera::CameraSettings& cam, uint32_t width, uint32_t height, const double* background, bool background_rows,
                 pt_rect slice, uint32_t samples, uint64_t seed, int sample_mode, bool collect_stats, uint8_t* rgb, double* linear,
                 pt_stats* stats);
-    pt_context* context() const { return ctx_; }
+    pt_context* context() const { return ctx_; }  // rank 0's context when the scene is on a node
+    pt_node* node() const { return node_; }
     const FlatScene& flat() const { return flat_; }
+    struct PrepareMs { double flatten = 0, pack = 0, context = 0, kd_build = 0, upload = 0; };  // where the time before the first pixel goes
+    const PrepareMs& prepare_ms() const { return prep_; }
 
    private:
     FlatScene flat_;
     pt_context* ctx_ = nullptr;
+    pt_node* node_ = nullptr;  // PORTRAYER_GPUS > 1: the render is tile-partitioned over the node's GPUs (one RCCL gather)
+    PrepareMs prep_;
 };
 
 // PNG codec for Image::new / Image::save (render.rs:165-208; the reference uses the `image` crate)

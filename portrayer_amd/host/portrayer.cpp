@@ -493,7 +493,29 @@ static void check(pt_context* ctx, int rc, const char* what) {
     throw std::runtime_error(msg);
 }
 
-Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, int kd_depth, int device) : flat_(FlatScene::from(hier)) {
+// PORTRAYER_GPUS = N | all: tile-partition every render over N GPUs of the node (pt_node_*, one RCCL gather);
+// PORTRAYER_DEVICES = "0,1,..." names them (ranks may share a device: tests on a 1-GPU box). Default: one GPU.
+static std::vector<int> node_devices(int device) {
+    std::vector<int> devs;
+    if (const char* e = std::getenv("PORTRAYER_DEVICES")) {
+        std::stringstream ss(e);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) if (!tok.empty()) devs.push_back(std::atoi(tok.c_str()));
+        return devs;
+    }
+    const char* g = std::getenv("PORTRAYER_GPUS");
+    int n = !g ? 1 : (std::string(g) == "all" ? pt_device_count() : std::atoi(g));
+    if (n <= 1) return {device};
+    for (int i = 0; i < n; i++) devs.push_back(i);
+    return devs;
+}
+
+static double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
+
+Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, int kd_depth, int device) {
+    auto t_flat = std::chrono::steady_clock::now();
+    flat_ = FlatScene::from(hier);
+    prep_.flatten = ms_since(t_flat);
     auto t_pack = std::chrono::steady_clock::now();
     const size_t n = flat_.root.size();
     std::vector<double> trans(16 * n), inv(16 * n), nrm(16 * n);
@@ -653,14 +675,37 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
     }
 
     const bool verbose = std::getenv("PORTRAYER_VERBOSE") != nullptr;
-    if (verbose) std::fprintf(stderr, "[Renderer] pack scene arrays %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pack).count());
+    prep_.pack = ms_since(t_pack);
     auto t_ctx = std::chrono::steady_clock::now();
-    int rc = pt_context_create(device, &ctx_);
-    if (verbose) std::fprintf(stderr, "[Renderer] pt_context_create %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ctx).count());
+    const std::vector<int> devs = node_devices(device);
+    int rc;
+    if (devs.size() > 1) {
+        rc = pt_node_create((int)devs.size(), devs.data(), &node_);
+        if (rc == PT_OK) ctx_ = pt_node_context(node_, 0);
+    } else {
+        rc = pt_context_create(devs.empty() ? device : devs[0], &ctx_);
+    }
+    prep_.context = ms_since(t_ctx);
     if (rc != PT_OK) throw std::runtime_error("pt_context_create failed (" + std::to_string(rc) + "): no usable MI355X; this path has no CPU fallback");
+    auto upload = [&](int mode, const pt_kdtree* kd) {
+        auto t_up = std::chrono::steady_clock::now();
+        if (node_) {
+            int urc = pt_node_scene_upload(node_, &s, mode, kd);
+            if (urc != PT_OK) {
+                std::string msg = std::string("pt_node_scene_upload failed (") + std::to_string(urc) + "): " + pt_node_last_error(node_);
+                if (urc == PT_ERR_SLICE || urc == PT_ERR_SCENE) throw Panic(msg);
+                throw std::runtime_error(msg);
+            }
+        } else {
+            check(ctx_, pt_scene_upload(ctx_, &s, mode, kd), "pt_scene_upload");
+        }
+        prep_.upload = ms_since(t_up);
+    };
     try {
         if (traversal == render::Traversal::KdTree) {
+            auto t_kd = std::chrono::steady_clock::now();
             KdTree t = kd_scene_tree(flat_, kd_depth < 0 ? 10 : (size_t)kd_depth);
+            prep_.kd_build = ms_since(t_kd);
             pt_kdtree kd;
             std::memset(&kd, 0, sizeof kd);
             kd.n_nodes = (uint32_t)t.axis.size();
@@ -670,7 +715,7 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
             kd.root_min[0] = t.root_min.x; kd.root_min[1] = t.root_min.y; kd.root_min[2] = t.root_min.z;
             kd.root_max[0] = t.root_max.x; kd.root_max[1] = t.root_max.y; kd.root_max[2] = t.root_max.z;
             kd.max_depth = t.max_depth;
-            check(ctx_, pt_scene_upload(ctx_, &s, PT_TRAVERSE_KD, &kd), "pt_scene_upload");
+            upload(PT_TRAVERSE_KD, &kd);
         } else if (traversal == render::Traversal::Hier) {
             // scene.rs:80-120: the hierarchy itself. Every SceneNode on a path gets an index; a flattened node's chain
             // names them root first; equal hits go to whoever comes first depth-first, a node before its children -
@@ -681,19 +726,23 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
             s.n_graph_nodes = gp.n_graph_nodes;
             s.graph_trans = g_trans.data(); s.graph_invtrans = g_inv.data(); s.graph_normal_trans = g_nrm.data();
             s.node_chain_off = chain_off.data(); s.node_chain = chain.data(); s.node_dfs_rank = rank.data();
-            check(ctx_, pt_scene_upload(ctx_, &s, PT_TRAVERSE_HIER, nullptr), "pt_scene_upload");
+            upload(PT_TRAVERSE_HIER, nullptr);
         } else {
-            check(ctx_, pt_scene_upload(ctx_, &s, PT_TRAVERSE_FLAT, nullptr), "pt_scene_upload");
+            upload(PT_TRAVERSE_FLAT, nullptr);
         }
     } catch (...) {
-        pt_context_destroy(ctx_);
-        ctx_ = nullptr;
+        if (node_) pt_node_destroy(node_); else pt_context_destroy(ctx_);
+        node_ = nullptr; ctx_ = nullptr;
         throw;
     }
+    if (verbose)
+        std::fprintf(stderr, "[Renderer] flatten %.2f ms, pack %.2f ms, context %.2f ms, k-d build %.2f ms, upload (incl. device trees) %.2f ms\n", prep_.flatten,
+                     prep_.pack, prep_.context, prep_.kd_build, prep_.upload);
 }
 
 Renderer::~Renderer() {
-    if (ctx_) pt_context_destroy(ctx_);
+    if (node_) pt_node_destroy(node_);
+    else if (ctx_) pt_context_destroy(ctx_);
 }
 
 void Renderer::render(const camera::CameraSettings& cam, uint32_t width, uint32_t height, const double* background, bool background_rows,
@@ -705,6 +754,16 @@ void Renderer::render(const camera::CameraSettings& cam, uint32_t width, uint32_
     std::memset(&p, 0, sizeof p);
     p.width = width; p.height = height; p.slice = slice; p.samples = samples; p.seed = seed; p.sample_mode = sample_mode;
     p.background_rows = background_rows ? 1 : 0; p.tile_rank = 0; p.tile_ranks = 1; p.collect_stats = collect_stats ? 1 : 0;
+    if (node_) {
+        if (linear) throw std::runtime_error("the linear (pre-gamma) output is a single-GPU debugging aid: unset PORTRAYER_GPUS / PORTRAYER_DEVICES");
+        int rc = pt_node_render(node_, &pc, background, &p, rgb, stats);
+        if (rc != PT_OK) {
+            std::string msg = std::string("pt_node_render failed (") + std::to_string(rc) + "): " + pt_node_last_error(node_);
+            if (rc == PT_ERR_SLICE || rc == PT_ERR_SCENE) throw Panic(msg);
+            throw std::runtime_error(msg);
+        }
+        return;
+    }
     check(ctx_, pt_render(ctx_, &pc, background, &p, rgb, linear, stats), "pt_render");
 }
 

@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.po_render.restype = C.c_int
         _lib.po_render.argtypes = [C.POINTER(PoScene), C.POINTER(PoCamera), _dp, C.POINTER(PoRenderParams), _u8p, _dp, C.POINTER(PoStats)]
+        _lib.po_last_render_ms.restype = None
+        _lib.po_last_render_ms.argtypes = [_dp]
         _lib.po_cast_rays.restype = C.c_int
         _lib.po_cast_rays.argtypes = [C.POINTER(PoScene), C.c_int, C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _ip, _dp, _dp]
         _lib.po_color_rays.restype = C.c_int
@@ -271,6 +273,13 @@ def render(scene, cam: Camera, width: int, height: int, background: Optional[np.
     if rc != 0:
         raise RuntimeError(f"po_render failed: {rc}")
     return RenderResult(rgb, linear, st.as_dict())
+
+
+def last_render_ms():
+    """(scene conversion ms, pixel loop ms) of the last render() call: render.rs:115-126 / :127-150."""
+    out = np.zeros(2)
+    lib().po_last_render_ms(_p(out, _dp))
+    return float(out[0]), float(out[1])
 
 
 def cast_rays(scene, origins, directions, mode=MODE_FLAT, kd_depth=-1, kd_mesh_depth=-1):

@@ -17,10 +17,7 @@ def ctx():
     c.close()
 
 
-def ulp_diff(a, b):
-    a = np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
-    b = np.ascontiguousarray(b, dtype=np.float64).view(np.int64)
-    return np.abs(a - b)
+from ulp import assert_ulp, ulp_diff  # noqa: E402
 
 
 def test_device_arithmetic_is_ieee(ctx):
@@ -45,6 +42,22 @@ def test_device_pow_within_one_ulp(ctx):
     print(f"pow: {100.0 * (d == 0).mean():.3f} % bit-equal to glibc, max {d.max()} ulp")
 
 
+def test_device_atan2_acos_against_glibc(ctx):
+    """The other libm calls on the device: sphere texture coordinates (sphere.rs:57-60, pt_apply_maps) go through atan2 and
+    acos. Their results only select a texel, so a last-bit difference matters only on a texel boundary; the measured bound
+    is written here so that a device-library change shows."""
+    rng = np.random.default_rng(5)
+    n = 200000
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]  # points on the unit sphere, like hit points
+    got = ctx.math(4, -d[:, 2], d[:, 0]); exp = np.arctan2(-d[:, 2], d[:, 0])
+    da = ulp_diff(got, exp)
+    got = ctx.math(5, d[:, 1], d[:, 1]); exp = np.arccos(d[:, 1])
+    dc = ulp_diff(got, exp)
+    print(f"atan2: {100.0 * (da == 0).mean():.3f} % bit-equal to glibc, max {da.max()} ulp; acos: {100.0 * (dc == 0).mean():.3f} %, max {dc.max()} ulp")
+    assert_ulp(ctx.math(4, -d[:, 2], d[:, 0]), np.arctan2(-d[:, 2], d[:, 0]), 2, "atan2")
+    assert_ulp(ctx.math(5, d[:, 1], d[:, 1]), np.arccos(d[:, 1]), 2, "acos")
+
+
 SMALL = {"single-triangle": (160, 120), "primitives-simple": (182, 102), "macho-cows": (96, 96),
          "entering-the-mirror-dimension": (160, 120), "big-scene": (198, 102)}
 
@@ -67,7 +80,7 @@ def test_render_matches_oracle(ctx, oracle, name, mode):
     d = ulp_diff(linear, ref.linear)
     print(f"{name}/{mode}: linear bit-equal {100.0 * (d == 0).mean():.4f} %, max {d.max()} ulp; kernel {st['kernel_ms']:.2f} ms")
     assert np.array_equal(rgb, ref.rgb)
-    assert d.max() <= 64  # pow differences (<= 1 ulp each) through at most a few adds
+    assert_ulp(linear, ref.linear, 64, f"{name}/{mode}")  # pow differences (<= 1 ulp each) through at most a few adds
     if mode == "kd":  # same tree, same order; shadow rays stop at the first hit of a leaf, the oracle finishes the leaf
         assert st["n_analytic"] <= ref.stats["n_analytic"]
         if ref.stats["n_tri"] == 0:  # with meshes n_inner also counts the build's own triangle-tree nodes
@@ -106,4 +119,4 @@ def test_multisample_rng_and_slice(ctx, oracle):
     ref = oracle.render(ds.ps, cam, w, h, samples=4, seed=42, jitter=oracle.JITTER_RNG, mode=oracle.MODE_FLAT, rect=(10, 5, 99, 70), into=ref_into)
     assert np.array_equal(rgb, ref.rgb)
     assert (rgb[0, 0] == 7).all() and (rgb[71:, :] == 7).all(), "pixels outside the slice must be untouched (render.rs:135-138)"
-    assert ulp_diff(linear[5:71, 10:100], ref.linear[5:71, 10:100]).max() <= 64
+    assert_ulp(linear[5:71, 10:100], ref.linear[5:71, 10:100], 64)

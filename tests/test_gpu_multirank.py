@@ -115,3 +115,54 @@ def test_stack_overflow_is_reported_without_the_counting_build(H):
     env = dict(os.environ, PORTRAYER_STACK_CAP="2")
     out = subprocess.run([sys.executable, "-c", _OVERFLOW % (ROOT, HERE)], env=env, capture_output=True, text=True, timeout=300)
     assert "ERR" in out.stdout and "-6" in out.stdout and "overflow" in out.stdout, out.stdout + out.stderr
+
+
+# ---------------------------------------------------------------------------------------------------
+# pt_node_*: the product's own multi-GPU path (one context per rank, gather, untile) - here with every
+# rank on GPU 0 (RCCL needs distinct GPUs; with shared devices the gather is device-to-device copies)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_node_render_equals_single_context(oracle, H, ranks):
+    import device_glue
+    from example_scenes import EXAMPLES
+    scene, cam, _ = EXAMPLES["entering-the-mirror-dimension"]()
+    ds = device_glue.DeviceScene(scene, H.TRAVERSE_FLAT)
+    lib = H.lib()
+    w, h, rect = 173, 101, (3, 2, 170, 99)
+    bg = default_background(w, h)
+    ctx = H.Context()
+    ds.upload(ctx)
+    one = np.full((h, w, 3), 9, dtype=np.uint8)
+    device_glue.render(ctx, cam, w, h, samples=5, seed=2, sample_mode=H.SAMPLE_RNG, rect=rect, into=one)
+    ctx.close()
+    node = C.c_void_p()
+    devs = (C.c_int32 * ranks)(*([0] * ranks))
+    assert lib.pt_node_create(ranks, devs, C.byref(node)) == 0
+    assert lib.pt_node_ranks(node) == ranks and lib.pt_node_uses_rccl(node) == 0
+    assert lib.pt_node_scene_upload(node, C.byref(ds.struct), H.TRAVERSE_FLAT, None) == 0, lib.pt_node_last_error(node)
+    img = np.full((h, w, 3), 9, dtype=np.uint8)
+    p = H.PtRenderParams(w, h, H.PtRect(*rect), 5, 2, H.SAMPLE_RNG, 1, 0, 1, 1)
+    st = H.PtStats()
+    camera = device_glue.camera_struct(cam, w, h)
+    rc = lib.pt_node_render(node, C.byref(camera), bg.ctypes.data_as(H._dp), C.byref(p), img.ctypes.data_as(H._u8p), C.byref(st))
+    assert rc == 0, lib.pt_node_last_error(node)
+    assert np.array_equal(img, one)
+    ref = oracle.render(scene, cam, w, h, samples=5, seed=2, jitter=oracle.JITTER_RNG, mode=oracle.MODE_FLAT, rect=rect)
+    assert st.primary == ref.stats["primary"] and st.shadow == ref.stats["shadow"] and st.reflect == ref.stats["reflect"]
+    lib.pt_node_destroy(node)
+
+
+def test_host_renderer_on_a_node(host, H, monkeypatch):
+    """PORTRAYER_DEVICES puts detail::Renderer (what Image::render builds) on a node: same picture."""
+    sc = host.Scene.example("macho-cows", assets=ASSETS)
+    w, h = 160, 90
+    bg = default_background(w, h)
+    r1 = host.Renderer(sc, H.TRAVERSE_HIER)
+    a, _, _ = r1.render(sc.camera, w, h, bg, samples=2, seed=1, sample_mode=H.SAMPLE_RNG, want_linear=False)
+    r1.close()
+    monkeypatch.setenv("PORTRAYER_DEVICES", "0,0,0,0")
+    r4 = host.Renderer(sc, H.TRAVERSE_HIER)
+    assert r4.ranks == 4
+    b, _, _ = r4.render(sc.camera, w, h, bg, samples=2, seed=1, sample_mode=H.SAMPLE_RNG, want_linear=False)
+    r4.close()
+    assert np.array_equal(a, b)

@@ -69,6 +69,19 @@ def test_cpp_example_equals_dsl_example(oracle, name):
     assert np.array_equal(cpp.camera, host_glue.cam10(cam))
 
 
+@pytest.mark.parametrize("name", ["big-mesh", "big-soup"])
+def test_cpp_synthetic_scene_equals_dsl_scene(oracle, name):
+    """bench.py takes the SURVEY 8(d) synthetic workloads from the product's C++ generator (examples/big-scene.cpp);
+    the GPU parity tests take them from the test DSL. Same arrays (checked at n = 2: 8 cows)."""
+    from example_scenes import SYNTHETIC
+    from portrayer_amd import host
+    cpp = host.Scene.example("synthetic:" + name, assets=ASSETS, n=2)
+    scene, cam, size = SYNTHETIC[name](2)
+    ref, _ = oracle.arrays_from_dsl(scene)
+    assert_same_scene(cpp.export(), ref)
+    assert np.array_equal(cpp.camera, host_glue.cam10(cam))
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_builder_call_replay_matches_oracle_composition(oracle, name):
     scene, _, _ = EXAMPLES[name]()
