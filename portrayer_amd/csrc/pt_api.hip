@@ -58,8 +58,13 @@ __global__ void pt_math_kernel(int op, uint64_t n, const double* a, const double
 }
 
 __global__ void __launch_bounds__(256) pt_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+    // four independent 16-byte loads in flight per lane before the first store
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
@@ -639,7 +644,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.mkd = (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;
     v.mkd_box = mkd_box.empty() || getenv("PORTRAYER_KD_NO_CULL") ? nullptr : (const float*)c->mkd_box.p;
     v.mkd_item_box = v.mkd_box ? (const float*)c->mkd_item_box.p : nullptr;
-    v.mode = traverse == PT_TRAVERSE_KD ? PT_MODE_KD : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
+    v.mode = traverse == PT_TRAVERSE_KD ? (s->n_meshes == 0 ? PT_MODE_KD_NOMESH : PT_MODE_KD) : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
     if (traverse == PT_TRAVERSE_HIER) {  // the general walker (meshes and KDMesh trees compiled in), or its mesh-free instantiation
         v.mode = s->n_meshes == 0 ? PT_MODE_HIER_NOMESH : PT_MODE_HIER;
         v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
@@ -707,6 +712,7 @@ static hipError_t pt_dispatch(const PtRenderArgs& a, int waves, bool stats, int 
     case PT_MODE_FLAT_KDMESH: return pt_launch_mode_4(a, waves, stats, tex, n_cu, stream, grid, launch);
     case PT_MODE_HIER: return pt_launch_mode_5(a, waves, stats, tex, n_cu, stream, grid, launch);
     case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, waves, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, waves, stats, tex, n_cu, stream, grid, launch);
     default: return pt_launch_mode_1(a, waves, stats, tex, n_cu, stream, grid, launch);
     }
 }
@@ -1007,6 +1013,7 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     case PT_MODE_FLAT_KDMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT_KDMESH>())); break;
     case PT_MODE_HIER: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER>())); break;
     case PT_MODE_HIER_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER_NOMESH>())); break;
+    case PT_MODE_KD_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_KD_NOMESH>())); break;
     default: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT>())); break;
     }
     PT_HIP(c, hipGetLastError());

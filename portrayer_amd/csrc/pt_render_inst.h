@@ -15,3 +15,4 @@ PT_DECLARE_MODE_LAUNCHER(3);  // PT_MODE_FLAT_NOMESH
 PT_DECLARE_MODE_LAUNCHER(4);  // PT_MODE_FLAT_KDMESH
 PT_DECLARE_MODE_LAUNCHER(5);  // PT_MODE_HIER
 PT_DECLARE_MODE_LAUNCHER(6);  // PT_MODE_HIER_NOMESH
+PT_DECLARE_MODE_LAUNCHER(7);  // PT_MODE_KD_NOMESH

@@ -481,11 +481,11 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
     }
 }
 
-// KD mode: kdtree/node.rs:112-202. A pending far side is (node, start) = 3 words: its range end is
-// the start of the entry below it on the stack (or +inf), because the current `end` always equals
-// the plane parameter of the innermost straddled split whose near side is being walked.
+// The reference's k-d walk as ONE loop (either a split step or a leaf per iteration): kept for scenes WITH mesh instances,
+// where a leaf can hold a whole mesh-tree walk and the while-while form below made every lane wait for it (mirror KD 7.1 ->
+// 6.7 Gray/s, profiles/r02/notes.md).
 template <bool STATS, class Stack>
-PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
+PT_HD bool pt_trace_kd_mesh(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
     best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
     double start = PT_EPSILON, end = INFINITY;  // ray.rs:140
     int sp = 0;
@@ -551,10 +551,105 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
     }
 }
 
+// KD mode: kdtree/node.rs:112-202. A pending far side is (node, start) = 3 words: its range end is
+// the start of the entry below it on the stack (or +inf), because the current `end` always equals
+// the plane parameter of the innermost straddled split whose near side is being walked.
+//
+// "while-while" like the other walks: every lane first works through splits, culls and pops until it holds
+// a LEAF to test (or has finished), and only then do the lanes run the leaf code - the f32 boxes of the leaf's
+// references and the f64 primitive tests, an order of magnitude more instructions than a split step -
+// together. (A single loop that took either branch per iteration ran the leaf code for a few lanes at a
+// time while the lanes at splits waited: 40 of 64 lanes active, profiles/r02/notes.md.)
+// MESH = false compiles the mesh-instance paths out of the leaf test (scenes of analytic primitives).
+template <bool STATS, bool MESH = true, class Stack = PtStack>
+PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
+    best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
+    double start = PT_EPSILON, end = INFINITY;  // ray.rs:140
+    int sp = 0;
+    const int32_t NONE = -1;
+    int32_t cur = 0;
+    const double extent = sc.kd_extent;
+    const PtRay32 q = pt_ray32(ray);
+    for (;;) {
+        PtKdNode n;
+        float seg0 = 0.0f, seg1 = 0.0f;
+        bool finished = false;
+        for (;;) {  // until this lane holds a leaf whose bounds its segment reaches
+            if (cur == NONE) {  // next pending far side
+                if (sp == 0) { finished = true; break; }
+                start = pt_pop_f64(stk, sp);
+                cur = (int32_t)pt_pop(stk, sp);
+                if (sp == 0) end = INFINITY;
+                else { int peek = sp; end = pt_pop_f64(stk, peek); }
+            }
+            n = sc.kd[cur];
+            PT_WAVE_COUNT(4);
+            // The ray's segment [start, end), rounded outward, against conservative f32 boxes: first the union of
+            // everything below this tree node - a subtree the segment does not reach reports no hit, which is all
+            // the reference would find out by walking it - then, in a leaf, each referenced node's own box.
+            seg0 = (float)start; seg1 = (float)end;
+            seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
+            if (sc.kd_box && !pt_slab32_segment(sc.kd_box + 6 * (size_t)cur, sc.kd_box + 6 * (size_t)cur + 3, q, seg0, seg1)) {
+                if (STATS) cnt->kd_culled++;
+                cur = NONE;
+                continue;
+            }
+            if (n.axis < 0) break;  // a leaf to test
+            if (STATS) cnt->n_inner++;
+            double t_max = start + extent;                                   // node.rs:118
+            if (!pt_in_range(start, end, t_max)) t_max = end - PT_EPSILON;   // node.rs:121
+            double t_min = start + PT_EPSILON;                               // node.rs:124
+            double o = pt_axis(ray.o, n.axis), d = pt_axis(ray.d, n.axis);
+            bool s = ((o + d * t_min) - n.plane) >= 0.0;                     // infinite_plane.rs:27-35
+            bool e = ((o + d * t_max) - n.plane) >= 0.0;
+            if (s == e) { cur = s ? n.front : n.back; continue; }
+            double plane_t = (n.plane - o) / d;                              // node.rs:90-109
+            if (pt_in_range(start, end, plane_t)) {
+                if (sp + 3 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
+                pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));
+                pt_push_f64(stk, sp, plane_t);
+                cur = s ? n.front : n.back;
+                end = plane_t;
+                continue;
+            }
+            // node.rs:146-147 / :177-178: the reference panics here; report a miss for this subtree
+            if (STATS) cnt->kd_plane_miss++;
+            cur = NONE;
+        }
+        if (finished) return false;
+        // Leaf: ray.rs:87-99 fold over the leaf's nodes, reference order, strict ends
+        if (STATS) cnt->n_leaf++;
+        PT_WAVE_COUNT(5);
+        bool found = false;
+        // The reference's tree puts a node into every leaf its box touches (6.8 references per node on
+        // big-scene) and tests all of them. A node whose (padded, outward-rounded) world box the ray's
+        // segment [start, end) does not reach cannot report a hit in that range, so it is skipped before
+        // the f64 test: same answers, 60 instead of 2 exact tests per ray saved.
+        for (int32_t i = 0; i < n.count; i++) {
+            const uint32_t item = sc.kd_items[n.first + i];
+            if (sc.node_box) {
+                const float* b = sc.node_box + 6 * (size_t)(n.first + i);
+                if (STATS) cnt->n_bbox++;
+                if (!pt_slab32_segment(b, b + 3, q, seg0, seg1)) continue;
+            }
+            PtHit lb; lb.t = end; lb.node = PT_NO_HIT; lb.sub = 0;
+            if (pt_test_node<STATS, MESH>(sc, item, ray, start, lb, any, stk, sp, cnt)) {
+                best = lb; end = lb.t; found = true;
+                if (any) return true;
+                // the segment has shrunk: later references of this leaf are culled against the new end
+                seg1 = (float)end; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
+            }
+        }
+        if (found) return true;  // node.rs:153-157: the first side that hits wins
+        cur = NONE;
+    }
+}
+
 // Traversal of one ray in the semantics of `MODE` (PT_MODE_*).
 template <int MODE, bool STATS, class Stack>
 PT_HD void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const Stack& stk, PtCounters* cnt) {
-    if (MODE == PT_MODE_KD) pt_trace_kd<STATS>(sc, ray, any, hit, stk, cnt);
+    if (MODE == PT_MODE_KD) pt_trace_kd_mesh<STATS>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_KD_NOMESH) pt_trace_kd<STATS, false>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_HIER) pt_trace_flat<STATS, true, true, true>(sc, ray, any, hit, stk, cnt);

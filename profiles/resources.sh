@@ -1,12 +1,12 @@
 #!/bin/bash
 # VGPRs / spills / scratch of every render-kernel instantiation (hipcc -Rpass-analysis=kernel-resource-usage).
 # usage: bash profiles/resources.sh [extra hipcc flags]
-for m in 1 2 3 4 5 6; do
+for m in 1 2 3 4 5 6 7; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-value "$@" -DPT_INST_MODE=$m \
       --cuda-device-only -Rpass-analysis=kernel-resource-usage -c portrayer_amd/csrc/pt_render_inst.hip -o /dev/null 2> /tmp/pt_res_$m.txt ) &
 done
 wait
-for m in 1 2 3 4 5 6; do python3 - $m <<'PY'
+for m in 1 2 3 4 5 6 7; do python3 - $m <<'PY'
 import re, sys
 t = open('/tmp/pt_res_%s.txt' % sys.argv[1]).read()
 for blk in t.split('remark: Function Name: ')[1:]:

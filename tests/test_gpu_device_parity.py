@@ -55,7 +55,7 @@ def test_device_atan2_acos_against_glibc(ctx):
     dc = ulp_diff(got, exp)
     print(f"atan2: {100.0 * (da == 0).mean():.3f} % bit-equal to glibc, max {da.max()} ulp; acos: {100.0 * (dc == 0).mean():.3f} %, max {dc.max()} ulp")
     assert_ulp(ctx.math(4, -d[:, 2], d[:, 0]), np.arctan2(-d[:, 2], d[:, 0]), 2, "atan2")
-    assert_ulp(ctx.math(5, d[:, 1], d[:, 1]), np.arccos(d[:, 1]), 2, "acos")
+    assert_ulp(ctx.math(5, d[:, 1], d[:, 1]), np.arccos(d[:, 1]), 1, "acos")
 
 
 SMALL = {"single-triangle": (160, 120), "primitives-simple": (182, 102), "macho-cows": (96, 96),
@@ -80,7 +80,7 @@ def test_render_matches_oracle(ctx, oracle, name, mode):
     d = ulp_diff(linear, ref.linear)
     print(f"{name}/{mode}: linear bit-equal {100.0 * (d == 0).mean():.4f} %, max {d.max()} ulp; kernel {st['kernel_ms']:.2f} ms")
     assert np.array_equal(rgb, ref.rgb)
-    assert_ulp(linear, ref.linear, 64, f"{name}/{mode}")  # pow differences (<= 1 ulp each) through at most a few adds
+    assert_ulp(linear, ref.linear, 8, f"{name}/{mode}")  # pow differences (<= 1 ulp each) through at most a few adds: measured max 4 ulp over the whole suite (gpurun_out/ulp_report.txt)
     if mode == "kd":  # same tree, same order; shadow rays stop at the first hit of a leaf, the oracle finishes the leaf
         assert st["n_analytic"] <= ref.stats["n_analytic"]
         if ref.stats["n_tri"] == 0:  # with meshes n_inner also counts the build's own triangle-tree nodes
@@ -119,4 +119,4 @@ def test_multisample_rng_and_slice(ctx, oracle):
     ref = oracle.render(ds.ps, cam, w, h, samples=4, seed=42, jitter=oracle.JITTER_RNG, mode=oracle.MODE_FLAT, rect=(10, 5, 99, 70), into=ref_into)
     assert np.array_equal(rgb, ref.rgb)
     assert (rgb[0, 0] == 7).all() and (rgb[71:, :] == 7).all(), "pixels outside the slice must be untouched (render.rs:135-138)"
-    assert_ulp(linear[5:71, 10:100], ref.linear[5:71, 10:100], 64)
+    assert_ulp(linear[5:71, 10:100], ref.linear[5:71, 10:100], 8)
