@@ -381,18 +381,33 @@ PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool an
 // continues in the mesh's tree; popping the marker switches back. Lanes inside a mesh and lanes in
 // the scene tree therefore share the inner-node code instead of waiting for each other.
 #define PT_REF_MARKER 0xFFFFFFFEu
+// The walk of the build's two-level bounding-volume tree as a resumable machine: begin() takes a ray, every step() is one
+// round of the "while-while" loop - down through inner nodes to a leaf, the leaf's candidates, the next pending subtree -
+// and returns true once the ray is finished (result in `best`). pt_render_kernel drives it so that a lane whose ray is
+// finished can take its NEXT ray while its neighbours are still walking (pt_render_kernel.h); pt_trace_flat() below runs
+// it to the end for one ray.
 // MESH = false compiles the mesh-instance path out (scenes of analytic primitives and stand-alone
 // triangles only): fewer live registers in the hot loop.
-template <bool STATS, bool MESH, bool KDMESH = MESH, bool HIER = false, class Stack = PtStack>
-PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
-    best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
-    if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return false;
-    int sp = 0;
-    PtRay32 q = pt_ray32(ray);
-    PtRay local = ray;            // model-space ray of the mesh instance being walked
-    uint32_t inst = PT_NO_HIT;    // flat node index of that instance, PT_NO_HIT while in the scene tree
-    uint32_t cur = sc.tlas_root;
-    for (;;) {
+template <bool MESH, bool KDMESH = MESH, bool HIER = false>
+struct PtBvhWalker {
+    PtHit best;
+    int sp;
+    uint32_t cur;
+    PtRay32 q;
+    PtRay local;    // model-space ray of the mesh instance being walked
+    uint32_t inst;  // flat node index of that instance, PT_NO_HIT while in the scene tree
+
+    PT_HD bool begin(const PtSceneView& sc, const PtRay& ray) {  // false: nothing to walk, the ray is finished (a miss)
+        best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
+        sp = 0; inst = PT_NO_HIT; cur = sc.tlas_root;
+        if (MESH) local = ray;
+        if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return false;
+        q = pt_ray32(ray);
+        return true;
+    }
+
+    template <bool STATS, class Stack>
+    PT_HD bool step(const PtSceneView& sc, const PtRay& ray, bool any, const Stack& stk, PtCounters* cnt) {
         while (!(cur & PT_REF_LEAF)) {
             const PtBvhNode& n = sc.bvh[cur];
             if (STATS) cnt->n_inner++;
@@ -404,7 +419,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
             uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
-                if (sp + 1 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
+                if (sp + 1 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return true; }
                 pt_push(stk, sp, swap ? c0 : c1);
                 cur = swap ? c1 : c0;
             } else if (h0) {
@@ -446,7 +461,7 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                     const PtMeshInfo& m = sc.meshes[data];
                     if (STATS) cnt->n_bbox++;
                     if (m.blas_root == PT_REF_EMPTY || !pt_bbox_test_hit(m.bbox_inv, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, item, 0))) continue;
-                    if (sp + 2 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return false; }
+                    if (sp + 2 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return true; }
                     // remaining items of this leaf (scene leaves hold one node unless PORTRAYER_TLAS_LEAF > 1)
                     if (i + 1 < count) pt_push(stk, sp, PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2));
                     pt_push(stk, sp, PT_REF_MARKER);
@@ -469,30 +484,65 @@ PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHi
                     }
                 }
             }
-            if (entered) continue;
+            if (entered) return false;
         }
         // next pending subtree
         for (;;) {
-            if (sp == 0) return best.node != PT_NO_HIT;
+            if (sp == 0) return true;
             cur = pt_pop(stk, sp);
             if (!MESH || cur != PT_REF_MARKER) break;
             q = pt_ray32(ray); inst = PT_NO_HIT;  // leaving the mesh instance: back to the world-space ray
         }
+        return false;
     }
+};
+
+// FLAT mode: nearest hit over [EPSILON, inf) (ray.rs:139-141), or any hit for shadow rays (material.rs:174-179 only
+// asks is_none()), for ONE ray.
+template <bool STATS, bool MESH, bool KDMESH = MESH, bool HIER = false, class Stack = PtStack>
+PT_HD bool pt_trace_flat(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
+    PtBvhWalker<MESH, KDMESH, HIER> w;
+    if (w.begin(sc, ray))
+        while (!w.template step<STATS>(sc, ray, any, stk, cnt)) {}
+    best = w.best;
+    return best.node != PT_NO_HIT;
 }
 
-// The reference's k-d walk as ONE loop (either a split step or a leaf per iteration): kept for scenes WITH mesh instances,
-// where a leaf can hold a whole mesh-tree walk and the while-while form below made every lane wait for it (mirror KD 7.1 ->
-// 6.7 Gray/s, profiles/r02/notes.md).
-template <bool STATS, class Stack>
-PT_HD bool pt_trace_kd_mesh(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
-    best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
-    double start = PT_EPSILON, end = INFINITY;  // ray.rs:140
-    int sp = 0;
-    int32_t cur = 0;
-    const double extent = sc.kd_extent;
-    const PtRay32 q = pt_ray32(ray);
-    for (;;) {
+// The reference's k-d walk (kdtree/node.rs:112-202) as a resumable machine like PtBvhWalker. A pending far side is
+// (node, start) = 3 words: its range end is the start of the entry below it on the stack (or +inf), because the current
+// `end` always equals the plane parameter of the innermost straddled split whose near side is being walked.
+//
+// MESH = false (scenes of analytic primitives): "while-while" - a step works through splits, culls and pops until the
+// lane holds a LEAF, then the lanes run the leaf code (the f32 boxes of the leaf's references and the f64 primitive
+// tests, an order of magnitude more instructions than a split step) together.
+// MESH = true: a step is ONE node, split or leaf - with mesh instances a leaf can hold a whole mesh-tree walk, and the
+// while-while form made every lane wait for it (mirror KD 7.1 -> 6.7 Gray/s, profiles/r02/notes.md).
+template <bool MESH>
+struct PtKdWalker {
+    PtHit best;
+    double start, end;
+    int sp;
+    int32_t cur;
+    PtRay32 q;
+    static constexpr int32_t NONE = -1;
+
+    PT_HD bool begin(const PtSceneView& sc, const PtRay& ray) {
+        best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
+        start = PT_EPSILON; end = INFINITY;  // ray.rs:140
+        sp = 0; cur = 0;
+        q = pt_ray32(ray);
+        return true;
+    }
+
+    template <bool STATS, class Stack>
+    PT_HD bool step(const PtSceneView& sc, const PtRay& ray, bool any, const Stack& stk, PtCounters* cnt) {
+        const double extent = sc.kd_extent;
+        if (MESH) return step_one_node<STATS>(sc, ray, any, stk, cnt, extent);
+        return step_to_leaf<STATS>(sc, ray, any, stk, cnt, extent);
+    }
+
+    template <bool STATS, class Stack>
+    PT_HD bool step_one_node(const PtSceneView& sc, const PtRay& ray, bool any, const Stack& stk, PtCounters* cnt, const double extent) {
         const PtKdNode n = sc.kd[cur];
         // The ray's segment [start, end), rounded outward, against conservative f32 boxes: first the union of
         // everything below this tree node - a subtree the segment does not reach reports no hit, which is all
@@ -530,47 +580,29 @@ PT_HD bool pt_trace_kd_mesh(const PtSceneView& sc, const PtRay& ray, bool any, P
             double o = pt_axis(ray.o, n.axis), d = pt_axis(ray.d, n.axis);
             bool s = ((o + d * t_min) - n.plane) >= 0.0;                     // infinite_plane.rs:27-35
             bool e = ((o + d * t_max) - n.plane) >= 0.0;
-            if (s == e) { cur = s ? n.front : n.back; continue; }
+            if (s == e) { cur = s ? n.front : n.back; return false; }
             double plane_t = (n.plane - o) / d;                              // node.rs:90-109
             if (pt_in_range(start, end, plane_t)) {
-                if (sp + 3 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 3 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return true; }
                 pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));
                 pt_push_f64(stk, sp, plane_t);
                 cur = s ? n.front : n.back;
                 end = plane_t;
-                continue;
+                return false;
             }
             // node.rs:146-147 / :177-178: the reference panics here; report a miss for this subtree
             if (STATS) cnt->kd_plane_miss++;
         }
-        if (sp == 0) return false;
+        if (sp == 0) { return true; }
         start = pt_pop_f64(stk, sp);
         cur = (int32_t)pt_pop(stk, sp);
         if (sp == 0) end = INFINITY;
         else { int peek = sp; end = pt_pop_f64(stk, peek); }
+        return false;
     }
-}
 
-// KD mode: kdtree/node.rs:112-202. A pending far side is (node, start) = 3 words: its range end is
-// the start of the entry below it on the stack (or +inf), because the current `end` always equals
-// the plane parameter of the innermost straddled split whose near side is being walked.
-//
-// "while-while" like the other walks: every lane first works through splits, culls and pops until it holds
-// a LEAF to test (or has finished), and only then do the lanes run the leaf code - the f32 boxes of the leaf's
-// references and the f64 primitive tests, an order of magnitude more instructions than a split step -
-// together. (A single loop that took either branch per iteration ran the leaf code for a few lanes at a
-// time while the lanes at splits waited: 40 of 64 lanes active, profiles/r02/notes.md.)
-// MESH = false compiles the mesh-instance paths out of the leaf test (scenes of analytic primitives).
-template <bool STATS, bool MESH = true, class Stack = PtStack>
-PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
-    best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
-    double start = PT_EPSILON, end = INFINITY;  // ray.rs:140
-    int sp = 0;
-    const int32_t NONE = -1;
-    int32_t cur = 0;
-    const double extent = sc.kd_extent;
-    const PtRay32 q = pt_ray32(ray);
-    for (;;) {
+    template <bool STATS, class Stack>
+    PT_HD bool step_to_leaf(const PtSceneView& sc, const PtRay& ray, bool any, const Stack& stk, PtCounters* cnt, const double extent) {
         PtKdNode n;
         float seg0 = 0.0f, seg1 = 0.0f;
         bool finished = false;
@@ -605,7 +637,7 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
             if (s == e) { cur = s ? n.front : n.back; continue; }
             double plane_t = (n.plane - o) / d;                              // node.rs:90-109
             if (pt_in_range(start, end, plane_t)) {
-                if (sp + 3 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; return false; }
+                if (sp + 3 > pt_stack_total(stk)) { pt_stack_overflow(stk); if (STATS) cnt->stack_overflow++; best.node = PT_NO_HIT; return true; }
                 pt_push(stk, sp, (uint32_t)(s ? n.back : n.front));
                 pt_push_f64(stk, sp, plane_t);
                 cur = s ? n.front : n.back;
@@ -616,7 +648,7 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
             if (STATS) cnt->kd_plane_miss++;
             cur = NONE;
         }
-        if (finished) return false;
+        if (finished) return true;
         // Leaf: ray.rs:87-99 fold over the leaf's nodes, reference order, strict ends
         if (STATS) cnt->n_leaf++;
         PT_WAVE_COUNT(5);
@@ -642,13 +674,23 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
         }
         if (found) return true;  // node.rs:153-157: the first side that hits wins
         cur = NONE;
+        return false;
     }
+};
+
+template <bool STATS, bool MESH = true, class Stack = PtStack>
+PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& best, const Stack& stk, PtCounters* cnt) {
+    PtKdWalker<MESH> w;
+    if (w.begin(sc, ray))
+        while (!w.template step<STATS>(sc, ray, any, stk, cnt)) {}
+    best = w.best;
+    return best.node != PT_NO_HIT;
 }
 
 // Traversal of one ray in the semantics of `MODE` (PT_MODE_*).
 template <int MODE, bool STATS, class Stack>
 PT_HD void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const Stack& stk, PtCounters* cnt) {
-    if (MODE == PT_MODE_KD) pt_trace_kd_mesh<STATS>(sc, ray, any, hit, stk, cnt);
+    if (MODE == PT_MODE_KD) pt_trace_kd<STATS, true>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_KD_NOMESH) pt_trace_kd<STATS, false>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);
