@@ -11,7 +11,8 @@ CXXFLAGS ?= -O2 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra 
 HOST := portrayer_amd/host
 HOST_SRCS := $(HOST)/portrayer.cpp $(HOST)/jpeg.cpp $(HOST)/capi.cpp $(wildcard examples/*.cpp)
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) examples/examples.hpp include/portrayer_host.h include/portrayer_hip.h
-EXAMPLES := single-triangle primitives-simple macho-cows entering-the-mirror-dimension big-scene smooth-shading glossy-reflection soft-shadows hier instance antialiasing fish normal-mapping transmission-refraction water-glass
+EXAMPLES := single-triangle primitives-simple macho-cows entering-the-mirror-dimension big-scene smooth-shading glossy-reflection soft-shadows hier instance antialiasing fish normal-mapping transmission-refraction water-glass \
+            simple nonhier nonhier2 four-shapes graphics-poster simple-cows primitives texture-mapping cube-mapping graphics-castle graphics-temple monkeys-making-monkeys robot-alarm-clock
 
 all: portrayer_amd/libportrayer_hip.so portrayer_amd/libportrayer_host.so $(addprefix examples/bin/,$(EXAMPLES))
 

@@ -70,6 +70,11 @@ int ph_scene_export(const ph_scene *scene, double *node_trans /* x16 */, int32_t
                     uint64_t *mesh_vert_off, uint64_t *mesh_tri_off, double *mesh_positions, double *mesh_normals, uint8_t *mesh_has_normals,
                     uint32_t *mesh_indices, double *tri_vertices, double *tri_normals, uint8_t *tri_has_normals,
                     double *materials, double *lights, double ambient[3]);
+/* Textures, normal maps and texture coordinates in ph_scene_export's numbering (materials / meshes / triangles in order of
+ * first use). counts = {n_textures, texel bytes}; call once with NULL arrays for the counts. */
+int ph_scene_export_textures(const ph_scene *s, uint64_t counts[2], int32_t *material_texture, int32_t *material_normal_map,
+                             double *material_uv_trans, uint32_t *texture_size, uint64_t *texture_offset, uint8_t *texture_rgb,
+                             double *mesh_texcoords, uint8_t *mesh_has_texcoords, double *tri_texcoords, uint8_t *tri_has_texcoords);
 
 /* FlatScene::from (flat_scene.rs:18-46): returns the number of flat nodes; fills up to cap entries. */
 int ph_scene_flatten(const ph_scene *scene, uint32_t cap, double *trans, double *invtrans, double *normal_trans,

@@ -17,7 +17,7 @@ DEFAULT_ASSETS = os.path.join(REPO_ROOT, "tests", "golden", "assets")
 
 _dp, _ip, _up, _u64p, _u8p = H._dp, H._ip, H._up, H._u64p, H._u8p
 
-EXPORTS = ["ph_last_error", "ph_scene_create", "ph_example_scene", "ph_scene_destroy", "ph_scene_counts", "ph_scene_export",
+EXPORTS = ["ph_last_error", "ph_scene_create", "ph_example_scene", "ph_scene_destroy", "ph_scene_counts", "ph_scene_export", "ph_scene_export_textures",
            "ph_scene_flatten", "ph_scene_kdtree", "ph_camera", "ph_obj_load", "ph_renderer_create", "ph_renderer_destroy",
            "ph_renderer_context", "ph_renderer_ranks", "ph_renderer_prepare_ms", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write", "ph_image_read", "ph_scene_graph"]
 
@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
         l.ph_renderer_prepare_ms.restype = C.c_int; l.ph_renderer_prepare_ms.argtypes = [vp, _dp]
         l.ph_renderer_render.restype = C.c_int
         l.ph_renderer_render.argtypes = [vp, _dp, C.POINTER(H.PtRenderParams), _dp, _u8p, _dp, C.POINTER(H.PtStats)]
+        l.ph_scene_export_textures.restype = C.c_int
+        l.ph_scene_export_textures.argtypes = [vp, _u64p, _ip, _ip, _dp, _up, _u64p, _u8p, _dp, _u8p, _dp, _u8p]
         l.ph_example_render_to_png.restype = C.c_int
         l.ph_example_render_to_png.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_char_p]
         l.ph_png_read.restype = C.c_int; l.ph_png_read.argtypes = [C.c_char_p, _up, _u8p, C.c_uint64]
@@ -173,6 +175,19 @@ class Scene:
                                      _p(a["tri_vertices"], _dp), _p(a["tri_normals"], _dp), _p(a["tri_has_normals"], _u8p),
                                      _p(a["materials"], _dp), _p(a["lights"], _dp), _p(a["ambient"], _dp)), "ph_scene_export")
         a.update(root=root.value, n_meshes=nm, n_triangles=nt, n_materials=nmat, n_lights=nl)
+        tc = np.zeros(2, dtype=np.uint64)
+        _check(lib().ph_scene_export_textures(self._h, _p(tc, _u64p), None, None, None, None, None, None, None, None, None, None), "ph_scene_export_textures")
+        ntex, nbytes = int(tc[0]), int(tc[1])
+        if ntex:
+            t = dict(material_texture=np.zeros(max(nmat, 1), dtype=np.int32), material_normal_map=np.zeros(max(nmat, 1), dtype=np.int32),
+                     material_uv_trans=np.zeros((max(nmat, 1), 9)), texture_size=np.zeros((ntex, 2), dtype=np.uint32), texture_offset=np.zeros(ntex, dtype=np.uint64),
+                     texture_rgb=np.zeros(max(nbytes, 1), dtype=np.uint8), mesh_texcoords=np.zeros((max(nv, 1), 2)), mesh_has_texcoords=np.zeros(nm + 1, dtype=np.uint8),
+                     tri_texcoords=np.zeros((max(nt, 1), 6)), tri_has_texcoords=np.zeros(nt + 1, dtype=np.uint8))
+            _check(lib().ph_scene_export_textures(self._h, _p(tc, _u64p), _p(t["material_texture"], _ip), _p(t["material_normal_map"], _ip),
+                                                  _p(t["material_uv_trans"], _dp), _p(t["texture_size"], _up), _p(t["texture_offset"], _u64p),
+                                                  _p(t["texture_rgb"], _u8p), _p(t["mesh_texcoords"], _dp), _p(t["mesh_has_texcoords"], _u8p),
+                                                  _p(t["tri_texcoords"], _dp), _p(t["tri_has_texcoords"], _u8p)), "ph_scene_export_textures")
+            a.update(t, n_textures=ntex)
         return a
 
     def flatten(self) -> dict:

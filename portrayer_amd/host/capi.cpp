@@ -172,6 +172,19 @@ static examples::Example make_example(const std::string& name, const std::string
     if (name == "normal-mapping") return examples::normal_mapping(assets);
     if (name == "transmission-refraction") return examples::transmission_refraction(assets);
     if (name == "water-glass") return examples::water_glass(assets);
+    if (name == "simple") return examples::simple();
+    if (name == "nonhier") return examples::nonhier(assets);
+    if (name == "nonhier2") return examples::nonhier2(assets);
+    if (name == "four-shapes") return examples::four_shapes();
+    if (name == "graphics-poster") return examples::graphics_poster(assets);
+    if (name == "simple-cows") return examples::simple_cows(assets);
+    if (name == "primitives") return examples::primitives(assets);
+    if (name == "texture-mapping") return examples::texture_mapping(assets);
+    if (name == "cube-mapping") return examples::cube_mapping(assets);
+    if (name == "graphics-castle") return examples::graphics_castle(assets);
+    if (name == "graphics-temple") return examples::graphics_temple(assets);
+    if (name == "monkeys-making-monkeys") return examples::monkeys_making_monkeys(assets);
+    if (name == "robot-alarm-clock") return examples::robot_alarm_clock(assets);
     throw std::runtime_error("unknown example scene: " + name);
 }
 
@@ -223,6 +236,61 @@ struct Linear {  // unique nodes in DFS pre-order, materials / meshes in order o
     }
 };
 }  // namespace
+
+// Textures, normal maps and texture coordinates of the scene, in the numbering of ph_scene_export (materials / meshes /
+// triangles in order of first use). Two calls: with texture_rgb == NULL it only fills counts = {n_textures, texel bytes}.
+extern "C" int ph_scene_export_textures(const ph_scene* s, uint64_t counts[2], int32_t* material_texture, int32_t* material_normal_map,
+                                        double* material_uv_trans, uint32_t* texture_size, uint64_t* texture_offset, uint8_t* texture_rgb,
+                                        double* mesh_texcoords, uint8_t* mesh_has_texcoords, double* tri_texcoords, uint8_t* tri_has_texcoords) {
+    if (!s || !counts) return bad("null argument");
+    return guarded([&]() -> int {
+        Linear lin(s->hier);
+        std::vector<const texture::RgbImageBuffer*> textures;
+        std::map<const texture::RgbImageBuffer*, int32_t> tex_id;
+        auto index = [&](const texture::RgbImageBuffer* b) {
+            auto it = tex_id.find(b);
+            if (it == tex_id.end()) { it = tex_id.emplace(b, (int32_t)textures.size()).first; textures.push_back(b); }
+            return it->second;
+        };
+        for (size_t i = 0; i < lin.mats.size(); i++) {
+            const material::Material* m = lin.mats[i];
+            int32_t a = m->texture ? index(&m->texture->image.buffer) : -1, b = m->normals ? index(&m->normals->buffer) : -1;
+            if (material_texture) material_texture[i] = a;
+            if (material_normal_map) material_normal_map[i] = b;
+            if (material_uv_trans) for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) material_uv_trans[9 * i + 3 * r + k] = m->uv_trans.m[r][k];
+        }
+        uint64_t off = 0;
+        for (size_t t = 0; t < textures.size(); t++) {
+            if (texture_size) { texture_size[2 * t] = (uint32_t)textures[t]->width; texture_size[2 * t + 1] = (uint32_t)textures[t]->height; }
+            if (texture_offset) texture_offset[t] = off;
+            if (texture_rgb) std::memcpy(texture_rgb + off, textures[t]->rgb.data(), textures[t]->rgb.size());
+            off += textures[t]->rgb.size();
+        }
+        counts[0] = textures.size(); counts[1] = off;
+        uint64_t vo = 0;
+        for (size_t m = 0; m < lin.meshes.size(); m++) {
+            const primitive::MeshData* md = lin.meshes[m];
+            const bool ht = md->tex_coords().size() == md->positions().size();
+            if (mesh_has_texcoords) mesh_has_texcoords[m] = ht ? 1 : 0;
+            if (mesh_texcoords)
+                for (size_t v = 0; v < md->positions().size(); v++) {
+                    mesh_texcoords[2 * (vo + v)] = ht ? md->tex_coords()[v].u : 0.0;
+                    mesh_texcoords[2 * (vo + v) + 1] = ht ? md->tex_coords()[v].v : 0.0;
+                }
+            vo += md->positions().size();
+        }
+        for (size_t t = 0; t < lin.tris.size(); t++) {
+            const primitive::Triangle* tr = lin.tris[t];
+            if (tri_has_texcoords) tri_has_texcoords[t] = tr->tex_coords ? 1 : 0;
+            if (tri_texcoords)
+                for (int k = 0; k < 3; k++) {
+                    tri_texcoords[6 * t + 2 * k] = tr->tex_coords ? (*tr->tex_coords)[k].u : 0.0;
+                    tri_texcoords[6 * t + 2 * k + 1] = tr->tex_coords ? (*tr->tex_coords)[k].v : 0.0;
+                }
+        }
+        return PH_OK;
+    });
+}
 
 extern "C" int ph_scene_counts(const ph_scene* s, uint64_t c[8]) {
     if (!s || !c) return bad("null argument");
@@ -457,7 +525,7 @@ extern "C" int ph_example_render_to_png(const char* name, const char* assets_dir
     return guarded([&]() -> int {
         examples::Example ex = make_example(name, assets_dir ? assets_dir : "assets", n);
         render::Image image = render::Image::create(png_path, width ? width : ex.width, height ? height : ex.height);
-        image.render<reporter::NullProgress>(ex.scene, ex.cam, examples::sky);
+        image.render<reporter::NullProgress>(ex.scene, ex.cam, ex.background);
         image.save();
         return PH_OK;
     });
@@ -501,7 +569,7 @@ extern "C" int ph_png_write(const char* path, uint32_t width, uint32_t height, c
 int portrayer::examples::run_main(Example ex) {
     try {
         render::Image image = render::Image::create(ex.output, ex.width, ex.height);
-        image.render<reporter::RenderProgress>(ex.scene, ex.cam, sky);
+        image.render<reporter::RenderProgress>(ex.scene, ex.cam, ex.background);
         image.save();
         const auto& st = image.last_stats();
         std::fprintf(stderr, "%s: kernel %.2f ms, total %.2f ms\n", ex.output.c_str(), st.kernel_ms, st.total_ms);

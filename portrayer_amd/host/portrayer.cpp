@@ -604,7 +604,13 @@ Renderer::Renderer(const scene::HierScene& hier, render::Traversal traversal, in
     {
         long kd_mesh_depth = 10;  // env KD_MESH_DEPTH, kdmesh.rs:51-53
         if (const char* e = std::getenv("KD_MESH_DEPTH")) { char* end = nullptr; long v = std::strtol(e, &end, 10); if (end && *end == 0 && v >= 0) kd_mesh_depth = v; }
-        for (size_t i = 0; i < n; i++) {
+        // PORTRAYER_KDMESH_AS_MESH=1: walk KDMesh primitives like Mesh. The reference's KDMesh classifies the sides of a split
+        // with a ray segment of length extent() = the SQUARED diagonal of the mesh's bounds (bounding_box.rs:95-99, "HACK"), so
+        // a KDMesh smaller than the distance to the camera loses most of its triangles (the script robot-alarm-clock.rs says
+        // "KDMesh doesn't work for this for some reason" about exactly such parts). Reproduced by default - this switch is for
+        // the picture the scene's author meant.
+        const bool kdmesh_as_mesh = std::getenv("PORTRAYER_KDMESH_AS_MESH") != nullptr;
+        for (size_t i = 0; i < n && !kdmesh_as_mesh; i++) {
             const auto& p = flat_.root[i].geometry.primitive;
             if (p.kind != primitive::Primitive::KDMeshK) continue;
             size_t mi = (size_t)mesh_id[p.mesh.get()];

@@ -1,5 +1,5 @@
 // rand 0.7.0 `StdRng` as the reference's scene scripts use it (examples/big-scene.rs:27-67):
-// `StdRng::seed_from_u64`, `gen::<f64>()`, `SliceRandom::choose`.
+// `StdRng::seed_from_u64`, `gen::<f64>()`, `SliceRandom::choose`, `SliceRandom::shuffle` (examples/graphics-castle.rs:452).
 //
 // rand / rand_chacha / rand_core are third-party crates (Cargo.lock pins rand 0.7.0, rand_chacha
 // 0.2.0, rand_core 0.5.0); this follows their published algorithms: seed_from_u64 fills the 32-byte
@@ -7,7 +7,9 @@
 // words 12-13 and stream 0; the output is the key-stream as little-endian 32-bit words.
 #pragma once
 
+#include <array>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace portrayer {
@@ -47,6 +49,11 @@ class StdRng {
     }
     template <class T>
     const T& choose(const std::vector<T>& v) { return v[gen_index((uint32_t)v.size())]; }
+    // SliceRandom::shuffle (rand 0.7.0 seq/mod.rs): for i in (1..len).rev() { swap(i, gen_index(rng, i + 1)) }
+    template <class T, size_t N>
+    void shuffle(std::array<T, N>& a) {
+        for (size_t i = N - 1; i >= 1; i--) std::swap(a[i], a[gen_index((uint32_t)(i + 1))]);
+    }
     const uint32_t* key() const { return key_; }
 
    private:
