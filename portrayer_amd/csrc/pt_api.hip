@@ -68,6 +68,37 @@ __global__ void __launch_bounds__(256) pt_copy_kernel(const double2* __restrict_
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// Two-child tree -> four-child tree (PtBvh4Node, pt_scene_view.h): node i takes over the children of its inner children.
+// One thread per two-child node; entries of the array that no tree uses (the device build reserves n - 1 nodes per mesh
+// and may need fewer) hold garbage, are never referenced, and are only kept from reading out of bounds.
+__global__ void __launch_bounds__(256) pt_collapse4_kernel(const PtBvhNode* __restrict__ bvh2, PtBvh4Node* __restrict__ bvh4, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PtBvhNode a = bvh2[i];
+    PtBvh4Node o;
+    int k = 0;
+    auto put = [&](const float* lo, const float* hi, uint32_t child) {
+        for (int ax = 0; ax < 3; ax++) { o.lo[ax][k] = lo[ax]; o.hi[ax][k] = hi[ax]; }
+        o.child[k] = child;
+        k++;
+    };
+    auto expand = [&](const float* lo, const float* hi, uint32_t child) {
+        if (child == PT_REF_EMPTY) return;
+        if ((child & PT_REF_LEAF) || child >= n) { put(lo, hi, child); return; }
+        const PtBvhNode c = bvh2[child];
+        if (c.child0 != PT_REF_EMPTY) put(c.lo0, c.hi0, c.child0);
+        if (c.child1 != PT_REF_EMPTY) put(c.lo1, c.hi1, c.child1);
+    };
+    expand(a.lo0, a.hi0, a.child0);
+    expand(a.lo1, a.hi1, a.child1);
+    for (; k < 4; k++) {
+        for (int ax = 0; ax < 3; ax++) { o.lo[ax][k] = (float)PT_BOX_LIMIT; o.hi[ax][k] = -(float)PT_BOX_LIMIT; }
+        o.child[k] = PT_REF_EMPTY;
+    }
+    o.pad[0] = o.pad[1] = o.pad[2] = o.pad[3] = 0u;
+    bvh4[i] = o;
+}
+
 // Second pass of a render: chunk sums -> pixels (one thread per pixel slot).
 __global__ void __launch_bounds__(PT_BLOCK) pt_finish_kernel(PtRenderArgs a) {
     uint32_t p = blockIdx.x * PT_BLOCK + threadIdx.x;
@@ -100,7 +131,7 @@ struct pt_context {
     int device = 0;
     int n_cu = 0;
     std::string err;
-    PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh_items, kd, kd_items;
+    PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh4, bvh_items, kd, kd_items;
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, mkd, mkd_items;
     PtBuf node_box, kd_box, mkd_box, mkd_item_box;
     PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank;  // PT_TRAVERSE_HIER: the scene graph
@@ -170,7 +201,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank};
+                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -550,6 +581,14 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         }
         if (verbose && !device_meshes.empty()) fprintf(stderr, "[pt_scene_upload] device tree build: %zu mesh(es), %.2f ms, %d clustering rounds, depth %d\n", device_meshes.size(), device_ms, rounds, max_blas_depth);
         lap("device mesh trees");
+        // the walks read the four-child form of every tree (scene tree and mesh trees alike)
+        if ((rc = pt_reserve(c, c->bvh4, std::max<size_t>(n_nodes, 1) * sizeof(PtBvh4Node)))) return rc;
+        if (n_nodes) {
+            hipLaunchKernelGGL(pt_collapse4_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, nullptr, (const PtBvhNode*)c->bvh.p, (PtBvh4Node*)c->bvh4.p, (uint32_t)n_nodes);
+            PT_HIP(c, hipGetLastError());
+            PT_HIP(c, hipDeviceSynchronize());
+        }
+        lap("four-child form");
     }
     if ((rc = pt_upload(c, c->g_inv, g_inv)) || (rc = pt_upload(c, c->g_fwd, g_fwd)) || (rc = pt_upload(c, c->g_nrm, g_nrm)) ||
         (rc = pt_upload(c, c->chain_off, chain_off)) || (rc = pt_upload(c, c->chain, chain)) || (rc = pt_upload(c, c->dfs_rank, dfs_rank)))
@@ -634,7 +673,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.info = (const uint32_t*)c->info.p; v.tri_v = (const double*)c->tri_v.p; v.tri_n = (const double*)c->tri_n.p;
     v.meshes = (const PtMeshInfo*)c->meshes.p; v.materials = (const double*)c->materials.p; v.lights = (const double*)c->lights.p;
     for (int k = 0; k < 3; k++) v.ambient[k] = s->ambient[k];
-    v.bvh = (const PtBvhNode*)c->bvh.p; v.bvh_items = (const uint32_t*)c->bvh_items.p;
+    v.bvh = (const PtBvhNode*)c->bvh.p; v.bvh4 = (const PtBvh4Node*)c->bvh4.p; v.bvh_items = (const uint32_t*)c->bvh_items.p;
     v.tlas_root = tlas.child; v.pad0 = 0;
     v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
     v.kd_extent = kd_extent;
@@ -657,8 +696,10 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     // The 4-wave instantiations stay selectable (PORTRAYER_WAVES=4) and tested.
     c->waves = 3;
     if (const char* e = getenv("PORTRAYER_WAVES")) c->waves = atoi(e) == 4 ? 4 : 3;
-    int below = std::max(max_blas_depth, 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
-    int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + below + 2 : tlas.depth + below + 4;
+    // a level of the four-child walk pushes up to three pending children and covers two levels of the two-child tree
+    auto wide = [](int depth2) { return 3 * ((depth2 + 1) / 2); };
+    int below = std::max(wide(max_blas_depth), 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
+    int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + below + 2 : wide(tlas.depth) + below + 4;
     v.stack_cap = std::max(cap, 8);
     if (const char* e = getenv("PORTRAYER_STACK_CAP")) v.stack_cap = std::max(1, atoi(e));  // tests: force PT_ERR_TRAVERSAL
     if (textured) {

@@ -35,6 +35,18 @@ struct PtBvhNode {
     uint32_t pad[2];
 };  // 64 bytes = four 16-byte loads
 
+// What the walks read: FOUR children per record. Built from the two-child tree by pulling every inner child's
+// own two children up one level (pt_collapse4_kernel): node i of this array holds the grandchildren of two-child
+// node i - a walk takes half as many DEPENDENT node fetches, and the fetch latency, not the box arithmetic, is
+// what a wavefront waits for between steps (profiles/r02/notes.md). Boxes as structure-of-arrays [axis][child] so
+// that the four slab tests read whole 16-byte vectors; unused slots have an inverted box (never hit) and
+// PT_REF_EMPTY. Child references are encoded as in PtBvhNode (an inner reference indexes THIS array).
+struct PtBvh4Node {
+    float lo[3][4], hi[3][4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};  // 128 bytes = one cache line
+
 struct PtKdNode {
     double plane;          // coordinate of the separating plane on `axis`
     int32_t axis;          // 0..2, or -1 for a leaf
@@ -69,7 +81,8 @@ struct PtSceneView {
     const double* materials;
     const double* lights;
     double ambient[3];
-    const PtBvhNode* bvh;
+    const PtBvhNode* bvh;     // the two-child tree as built (host binned SAH / device PLOC); the walks read bvh4
+    const PtBvh4Node* bvh4;   // its four-child form, same node indices
     const uint32_t* bvh_items;
     uint32_t tlas_root, pad0;
     const PtKdNode* kd;
