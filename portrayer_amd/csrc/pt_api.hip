@@ -776,7 +776,17 @@ static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_par
     uint32_t k = PT_SAMPLE_CHUNK;
     if (p->samples < PT_SAMPLE_CHUNK) { k = 1; while (k < p->samples) k *= 2; }
     a->lane_samples = k;
-    a->n_items = (a->n_slots / 64) * a->n_chunks * k;
+    // C chunks of a pixel side by side: the largest of 8, 4, 2, 1 that leaves at most 1/16 of the chunk slots empty
+    // (SAMPLES = 64: 8 chunks -> C = 8, one pixel per wavefront; SAMPLES = 16: C = 2; SAMPLES = 100, 13 chunks: C = 1)
+    uint32_t cc = 1;
+    if (k == PT_SAMPLE_CHUNK)
+        for (uint32_t cand = 8; cand > 1; cand /= 2) {
+            uint32_t slots = (a->n_chunks + cand - 1) / cand * cand;
+            if ((slots - a->n_chunks) * 16 <= a->n_chunks) { cc = cand; break; }
+        }
+    if (const char* e = getenv("PORTRAYER_LANE_CHUNKS")) { uint32_t v = (uint32_t)atoi(e); if (k == PT_SAMPLE_CHUNK && (v == 1 || v == 2 || v == 4 || v == 8)) cc = v; }
+    a->lane_chunks = cc;
+    a->n_items = (a->n_slots / 64) * ((a->n_chunks + cc - 1) / cc) * (k * cc);
     return PT_OK;
 }
 

@@ -70,8 +70,9 @@ struct PtRenderArgs {
     uint32_t tile_rank, tile_ranks;  // this launch renders 8x8 tiles t with t % tile_ranks == tile_rank
     uint32_t n_slots;                // pixel slots of this launch (own tiles x 64)
     uint32_t n_chunks;               // sample chunks per pixel: ceil(samples / PT_SAMPLE_CHUNK)
-    uint32_t lane_samples;           // K = samples that run side by side in a wavefront: 8, or the next power of two >= samples
-    uint32_t n_items;                // wavefront work items of this launch = own tiles x n_chunks x K (each: 64 / K pixels x K samples)
+    uint32_t lane_samples;           // K = samples of a chunk that run side by side in a wavefront: 8, or the next power of two >= samples
+    uint32_t lane_chunks;            // C = chunks of a pixel that run side by side (1, 2, 4 or 8); a wavefront covers 64 / (K C) pixels
+    uint32_t n_items;                // wavefront work items of this launch = own tiles x ceil(n_chunks / C) x (K C)
     double* accum;                   // n_slots x n_chunks x 3: per (tile, chunk, pixel) sum of the chunk's samples
     int32_t compact;                 // 1: rgb is tile-major over own tiles; 0: rgb is the full H x W x 3 image
     uint8_t* rgb;
@@ -123,34 +124,37 @@ PT_HD bool pt_slot_to_pixel(const PtRenderArgs& a, uint32_t p, uint32_t* x, uint
     *x = px; *y = py;
     return px <= a.x1 && py <= a.y1;
 }
-// Wavefront work item w = (local tile * n_chunks + chunk) * K + part, K = lane_samples: the wavefront's 64 lanes are
-// 64 / K pixels of the tile (part `part` of it) x K consecutive samples of the chunk, a pixel's samples in
-// neighbouring lanes. Pixels are taken in 4x2-block order - position q of the tile is block q / 8 (two blocks
-// per row of blocks), pixel q % 8 of the block - so that with K = 8 a wavefront's rays all pass through one
-// 4x2-pixel window: they walk the same part of the trees and take about the same number of steps.
+// Wavefront work item: the 64 lanes are P neighbouring pixels of an 8x8 tile x C consecutive 8-sample chunks x K samples
+// of a chunk (P C K = 64; K = lane_samples, C = lane_chunks), a chunk's samples in neighbouring lanes. With SAMPLES = 64
+// that is ONE pixel's 64 samples (P = 1, C = 8, K = 8): every ray of the wavefront passes through the same pixel, walks the
+// same part of the trees and takes about the same number of steps - which is what keeps the lanes of a wavefront busy
+// inside the walk (profiles/r02/notes.md). Item w = ((local tile * n_groups + chunk group) * (64 / P)) + part.
+// Pixels of a tile are taken in Morton order, so that P consecutive ones form a compact window (2x1, 2x2, 4x2, 4x4 ...).
 PT_HD uint32_t pt_tile_order_to_slot(uint32_t q) {  // -> j = y * 8 + x inside the 8x8 tile
-    uint32_t b = q >> 3, p = q & 7u;
-    uint32_t x = (b & 1u) * 4u + (p & 3u), y = (b >> 1) * 2u + (p >> 2);
+    uint32_t x = (q & 1u) | ((q >> 1) & 2u) | ((q >> 2) & 4u);
+    uint32_t y = ((q >> 1) & 1u) | ((q >> 2) & 2u) | ((q >> 3) & 4u);
     return y * 8u + x;
 }
 struct PtItemLane {
     uint32_t slot;    // pixel slot of this launch (local tile * 64 + j)
     uint32_t chunk;
     uint32_t sample;  // absolute sample index
-    uint32_t first;   // 1: this lane holds the first sample of its pixel in this chunk (it sums the chunk)
+    uint32_t first;   // 1: this lane holds the first sample of its pixel's chunk (it sums the chunk)
     uint32_t count;   // samples of this chunk (<= K)
 };
 PT_HD bool pt_item_lane(const PtRenderArgs& a, uint32_t w, uint32_t lane, PtItemLane* it, uint32_t* x, uint32_t* y) {
-    const uint32_t K = a.lane_samples, per = 64u / K;
-    uint32_t part = w % K, g = w / K;
-    uint32_t chunk = g % a.n_chunks, tile_local = g / a.n_chunks;
-    uint32_t pi = lane / K, si = lane % K;
-    uint32_t j = pt_tile_order_to_slot(part * per + pi);
+    const uint32_t K = a.lane_samples, C = a.lane_chunks, P = 64u / (K * C), parts = 64u / P;
+    const uint32_t n_groups = (a.n_chunks + C - 1u) / C;
+    uint32_t part = w % parts, g = w / parts;
+    uint32_t group = g % n_groups, tile_local = g / n_groups;
+    uint32_t si = lane % K, ci = (lane / K) % C, pi = lane / (K * C);
+    uint32_t j = pt_tile_order_to_slot(part * P + pi);
+    uint32_t chunk = group * C + ci;
     it->slot = (tile_local << 6) | j;
     it->chunk = chunk;
     it->sample = chunk * PT_SAMPLE_CHUNK + si;
     it->first = si == 0u;
-    uint32_t left = a.samples - chunk * PT_SAMPLE_CHUNK;
+    uint32_t left = chunk < a.n_chunks ? a.samples - chunk * PT_SAMPLE_CHUNK : 0u;
     it->count = left < (uint32_t)PT_SAMPLE_CHUNK ? left : (uint32_t)PT_SAMPLE_CHUNK;
     return pt_slot_to_pixel(a, it->slot, x, y) && si < it->count;
 }
