@@ -492,7 +492,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     }
     int tlas_leaf = 1;  // primitive tests (f64, ~200 instructions) cost far more than a node visit: measured best on big-scene
     if (const char* e = getenv("PORTRAYER_TLAS_LEAF")) tlas_leaf = std::max(1, atoi(e));
-    PtBvhRef tlas = pt_bvh_build(node_box.data(), nullptr, n, tlas_leaf, bvh, items);
+    const bool tlas_direct = tlas_leaf == 1 && n < (1u << 28);
+    PtBvhRef tlas = pt_bvh_build(node_box.data(), nullptr, n, tlas_leaf, bvh, items, tlas_direct);
 
     // ---- k-d tree (reference structure, KD mode)
     std::vector<PtKdNode> kdn;
@@ -674,7 +675,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.meshes = (const PtMeshInfo*)c->meshes.p; v.materials = (const double*)c->materials.p; v.lights = (const double*)c->lights.p;
     for (int k = 0; k < 3; k++) v.ambient[k] = s->ambient[k];
     v.bvh = (const PtBvhNode*)c->bvh.p; v.bvh4 = (const PtBvh4Node*)c->bvh4.p; v.bvh_items = (const uint32_t*)c->bvh_items.p;
-    v.tlas_root = tlas.child; v.pad0 = 0;
+    v.tlas_root = tlas.child; v.tlas_direct = tlas_direct ? 1u : 0u;
     v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
     v.kd_extent = kd_extent;
     v.node_box = traverse == PT_TRAVERSE_KD && !kdi.empty() ? (const float*)c->node_box.p : nullptr;

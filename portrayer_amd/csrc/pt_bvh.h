@@ -66,11 +66,18 @@ struct Builder {
     std::vector<uint32_t> order;  // permutation of local indices
     const uint32_t* ids;          // local index -> item id written to the items array
     int max_leaf;
+    bool direct = false;  // one item per leaf, named by the leaf reference itself (no entry in the items array)
     std::vector<PtBvhNode>* nodes;
     std::vector<uint32_t>* items;
 
     PtBvhRef leaf(size_t b, size_t e, const PtBuildBox& box) {
         PtBvhRef r;
+        if (direct) {
+            r.child = PT_REF_LEAF | ((ids ? ids[order[b]] : order[b]) << 3);
+            r.box = box;
+            r.depth = 1;
+            return r;
+        }
         r.child = PT_REF_LEAF | ((uint32_t)items->size() << 3) | (uint32_t)(e - b - 1);
         for (size_t i = b; i < e; i++) items->push_back(ids ? ids[order[i]] : order[i]);
         r.box = box;
@@ -150,10 +157,13 @@ struct Builder {
 
 // Builds a tree over boxes[0..n) and appends its nodes / leaf items to the shared arrays. `ids`
 // (optional) maps a local box index to the value stored in the items array.
+// `direct` (needs max_leaf == 1): a leaf reference carries its item instead of an index into `items` - one dependent
+// load less per leaf visit (the scene-level tree, whose leaves each hold one flattened node).
 inline PtBvhRef pt_bvh_build(const PtBuildBox* boxes, const uint32_t* ids, size_t n, int max_leaf,
-                             std::vector<PtBvhNode>& nodes, std::vector<uint32_t>& items) {
+                             std::vector<PtBvhNode>& nodes, std::vector<uint32_t>& items, bool direct = false) {
     pt_bvh_detail::Builder b;
     b.boxes = boxes; b.ids = ids; b.max_leaf = std::max(1, std::min(max_leaf, 8)); b.nodes = &nodes; b.items = &items;
+    b.direct = direct && b.max_leaf == 1 && n < (1u << 28);
     b.order.resize(n);
     for (size_t i = 0; i < n; i++) b.order[i] = (uint32_t)i;
     if (n == 0) {

@@ -99,7 +99,13 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
 #ifdef PT_DIAG
             if (STATS) { if (lane == 0) cnt.diag[2]++; if (active) cnt.diag[3]++; }
 #endif
+#ifdef PT_CYCLES
+            const unsigned long long cyc_a = __builtin_readcyclecounter();
+#endif
             if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH>(a, L, hit, fr, &cnt);
+#ifdef PT_CYCLES
+            const unsigned long long cyc_b = __builtin_readcyclecounter();
+#endif
             const bool tracing = L.stage != PT_ST_DONE && L.has_ray;
 #ifdef PT_DIAG
             if (STATS) {
@@ -109,6 +115,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
             }
 #endif
             if (tracing) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
+#ifdef PT_CYCLES
+            if (STATS && lane == 0) { const unsigned long long cyc_c = __builtin_readcyclecounter(); cnt.diag[2] += cyc_b - cyc_a; cnt.diag[0] += cyc_c - cyc_b; cnt.diag[1]++; }
+#endif
         }
         // render.rs:36-43 under the summation contract: the chunk's samples in ascending order. A pixel's samples sit
         // in neighbouring lanes; their colours are in the lanes' LDS columns (same wavefront: program order suffices).

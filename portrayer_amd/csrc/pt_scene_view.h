@@ -84,7 +84,8 @@ struct PtSceneView {
     const PtBvhNode* bvh;     // the two-child tree as built (host binned SAH / device PLOC); the walks read bvh4
     const PtBvh4Node* bvh4;   // its four-child form, same node indices
     const uint32_t* bvh_items;
-    uint32_t tlas_root, pad0;
+    uint32_t tlas_root;
+    uint32_t tlas_direct;  // 1: a leaf of the scene-level tree names its flattened node in the reference itself (bits 30..3)
     const PtKdNode* kd;
     const uint32_t* kd_items;
     // PT_MODE_HIER (scene.rs:80-120): each SceneNode's OWN matrices and every flattened node's path through them

@@ -31,6 +31,15 @@
 #define PT_WAVE_COUNT(k) do { } while (0)
 #define PT_LANE_COUNT(k) do { } while (0)
 #endif
+// -DPT_CYCLES (profiles/cycles.sh): shader cycles a wavefront spends in a section, summed over wavefronts into diag[k]
+// (only lane 0 of a wave adds; s_memtime itself costs ~10 % of wave cycles, so read the split, not the totals)
+#ifdef PT_CYCLES
+#define PT_CYC_BEGIN() const unsigned long long pt_cyc0_ = __builtin_readcyclecounter()
+#define PT_CYC_END(k) do { if (STATS && (__lane_id() == 0 || __ffsll((long long)__ballot(1)) - 1 == (int)__lane_id())) cnt->diag[k] += __builtin_readcyclecounter() - pt_cyc0_; } while (0)
+#else
+#define PT_CYC_BEGIN() do { } while (0)
+#define PT_CYC_END(k) do { } while (0)
+#endif
 
 struct PtHit {
     double t;       // ray parameter of the best hit so far; doubles as the exclusive range end
@@ -275,7 +284,7 @@ PT_HD bool pt_bvh2_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, c
         }
         if (STATS) cnt->n_leaf++;
         PT_WAVE_COUNT(5);
-        if (leaf((cur & ~PT_REF_LEAF) >> 3, (cur & 7u) + 1u, sp)) return true;
+        { PT_CYC_BEGIN(); const bool stop_ = leaf((cur & ~PT_REF_LEAF) >> 3, (cur & 7u) + 1u, sp); PT_CYC_END(5); if (stop_) return true; }
         if (sp == sp0) return false;
         cur = pt_pop(stk, sp);
     }
@@ -443,7 +452,7 @@ PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool an
     pt_bvh2_walk<STATS>(sc.bvh, sc.tlas_root, ray, best.t, stk, 0,
         [&](uint32_t first, uint32_t count, int sp) -> bool {
             for (uint32_t i = 0; i < count; i++) {
-                uint32_t node = sc.bvh_items[first + i];
+                uint32_t node = sc.tlas_direct ? first : sc.bvh_items[first + i];
                 if (pt_test_node<STATS, false>(sc, node, ray, PT_EPSILON, best, any, stk, sp, cnt) && any) return true;
             }
             return false;
@@ -541,7 +550,7 @@ struct PtBvhWalker {
             const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
             bool entered = false;
             for (uint32_t i = 0; i < count && !entered; i++) {
-                uint32_t item = sc.bvh_items[first + i];
+                uint32_t item = ((!MESH || inst == PT_NO_HIT) && sc.tlas_direct) ? first : sc.bvh_items[first + i];
                 if (MESH && inst != PT_NO_HIT) {  // a triangle of the current mesh instance (mesh.rs:157-166, triangle.rs:38-80)
                     double tt, beta, gamma;
                     if (STATS) cnt->n_tri++;
