@@ -357,7 +357,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         for (uint32_t i = 0; i < s->n_kdm_nodes; i++) {
             PtKdNode& k = mkd[i];
             k.axis = s->kdm_axis[i]; k.plane = s->kdm_plane[i]; k.front = s->kdm_front[i]; k.back = s->kdm_back[i];
-            k.first = s->kdm_first[i]; k.count = s->kdm_count[i]; k.pad = 0;
+            k.first = s->kdm_first[i]; k.count = s->kdm_count[i]; k.pad = 0; k.pad2[0] = k.pad2[1] = 0.0f; for (int r = 0; r < 6; r++) k.box[r] = 0.0f;
             if (k.axis >= 0) {
                 if (k.axis > 2 || k.front < 0 || k.back < 0 || (uint32_t)k.front >= s->n_kdm_nodes || (uint32_t)k.back >= s->n_kdm_nodes)
                     return pt_fail(c, PT_ERR_ARGUMENT, "KDMesh tree child out of range");
@@ -507,7 +507,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         for (uint32_t i = 0; i < kd->n_nodes; i++) {
             PtKdNode& k = kdn[i];
             k.axis = kd->axis[i]; k.plane = kd->plane[i]; k.front = kd->front[i]; k.back = kd->back[i];
-            k.first = kd->first[i]; k.count = kd->count[i]; k.pad = 0;
+            k.first = kd->first[i]; k.count = kd->count[i]; k.pad = 0; k.pad2[0] = k.pad2[1] = 0.0f; for (int r = 0; r < 6; r++) k.box[r] = 0.0f;
             if (k.axis >= 0) {
                 if (k.axis > 2 || k.front < 0 || k.back < 0 || (uint32_t)k.front >= kd->n_nodes || (uint32_t)k.back >= kd->n_nodes)
                     return pt_fail(c, PT_ERR_ARGUMENT, "k-d child out of range");
@@ -591,6 +591,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         }
         lap("four-child form");
     }
+    for (size_t i = 0; i < kdn.size() && !kd_box32.empty(); i++) for (int r = 0; r < 6; r++) kdn[i].box[r] = kd_box32[6 * i + r];
+    for (size_t i = 0; i < mkd.size() && !mkd_box.empty(); i++) for (int r = 0; r < 6; r++) mkd[i].box[r] = mkd_box[6 * i + r];
     if ((rc = pt_upload(c, c->g_inv, g_inv)) || (rc = pt_upload(c, c->g_fwd, g_fwd)) || (rc = pt_upload(c, c->g_nrm, g_nrm)) ||
         (rc = pt_upload(c, c->chain_off, chain_off)) || (rc = pt_upload(c, c->chain, chain)) || (rc = pt_upload(c, c->dfs_rank, dfs_rank)))
         return rc;

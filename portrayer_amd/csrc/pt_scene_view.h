@@ -53,7 +53,9 @@ struct PtKdNode {
     int32_t front, back;   // children (node.rs:20-22)
     int32_t first, count;  // leaf: kd_items[first .. first+count)
     int32_t pad;
-};  // 32 bytes
+    float box[6];          // union of the (padded, outward-rounded) boxes of everything below this node: the walk's conservative
+    float pad2[2];         //   cull reads it with the node (one 64-byte record, one fetch per step)
+};  // 64 bytes
 
 struct PtMeshInfo {
     double bbox_inv[12];   // rows 0..2 of BoundingBox::invtrans (bounding_box.rs:55-82)
@@ -95,7 +97,7 @@ struct PtSceneView {
     const uint32_t* chain_off;  // n_nodes + 1
     const uint32_t* chain;      // graph node indices, root first
     const uint32_t* dfs_rank;   // per flattened node: depth-first order, a node before its children (who wins equal hits)
-    const float* kd_box;     // KD mode: per k-d node, the union of the boxes of everything below it (6 f32, rounded outward); else null
+    const float* kd_box;     // KD mode: non-null = PtKdNode::box is valid and the walk culls with it (the array itself is a copy kept for tools); else null
     const float* node_box;   // KD mode: per kd_items entry, that node's padded world box as 6 f32 rounded outward (leaf pre-cull in pt_trace_kd); else null
     double kd_extent;  // bounding_box.rs:95-99: squared diagonal of the root bounds
     int32_t mode;

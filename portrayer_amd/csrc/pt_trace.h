@@ -339,7 +339,7 @@ PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay
         // conservative culls as in pt_trace_kd: a subtree / a triangle whose box the segment [start, end) does not reach reports no hit
         float seg0 = (float)start, seg1 = (float)end;
         seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
-        if (sc.mkd_box && !pt_slab32_segment(sc.mkd_box + 6 * (size_t)cur, sc.mkd_box + 6 * (size_t)cur + 3, q, seg0, seg1)) {
+        if (sc.mkd_box && !pt_slab32_segment(n.box, n.box + 3, q, seg0, seg1)) {
             if (STATS) cnt->kd_culled++;
         } else if (n.axis < 0) {  // leaf: [T]::ray_hit (ray.rs:50-63) over the leaf's triangles, in order, strict shrinking end
             if (STATS) cnt->n_leaf++;
@@ -662,7 +662,7 @@ struct PtKdWalker {
         // the reference would find out by walking it - then, in a leaf, each referenced node's own box.
         float seg0 = (float)start, seg1 = (float)end;
         seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
-        if (sc.kd_box && !pt_slab32_segment(sc.kd_box + 6 * (size_t)cur, sc.kd_box + 6 * (size_t)cur + 3, q, seg0, seg1)) {
+        if (sc.kd_box && !pt_slab32_segment(n.box, n.box + 3, q, seg0, seg1)) {
             if (STATS) cnt->kd_culled++;
         } else if (n.axis < 0) {  // Leaf: ray.rs:87-99 fold over the leaf's nodes, reference order, strict ends
             if (STATS) cnt->n_leaf++;
@@ -734,7 +734,7 @@ struct PtKdWalker {
             // the reference would find out by walking it - then, in a leaf, each referenced node's own box.
             seg0 = (float)start; seg1 = (float)end;
             seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
-            if (sc.kd_box && !pt_slab32_segment(sc.kd_box + 6 * (size_t)cur, sc.kd_box + 6 * (size_t)cur + 3, q, seg0, seg1)) {
+            if (sc.kd_box && !pt_slab32_segment(n.box, n.box + 3, q, seg0, seg1)) {
                 if (STATS) cnt->kd_culled++;
                 cur = NONE;
                 continue;
