@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -116,7 +117,10 @@ extern "C" int pt_node_create(int n_devices, const int* devices, pt_node** out) 
             return bail(PT_ERR_DEVICE);
     }
     std::set<int> distinct(n->devices.begin(), n->devices.end());
-    if (ranks > 1 && distinct.size() == ranks) {  // one GPU per rank: RCCL over xGMI
+    // PORTRAYER_NODE_RCCL=1: also for a single rank, so that a 1-GPU box can run the library loading, the communicator and
+    // the gather call as they are (tests); a node of one GPU has nothing to gather and skips RCCL otherwise
+    const bool lone_rank_too = getenv("PORTRAYER_NODE_RCCL") != nullptr;
+    if ((ranks > 1 || lone_rank_too) && distinct.size() == ranks) {  // one GPU per rank: RCCL over xGMI
         std::string e = g_rccl.load();
         if (!e.empty()) { fprintf(stderr, "pt_node_create: %s\n", e.c_str()); return bail(PT_ERR_DEVICE); }
         n->comm.assign(ranks, nullptr);

@@ -1,5 +1,5 @@
 // One traversal mode's instantiations of pt_render_kernel (counting / plain, textured / untextured,
-// 3 / 4 waves per SIMD) and their launcher. Compiled six times: -DPT_INST_MODE=1..6 (Makefile).
+// 3 / 4 waves per SIMD) and their launcher. Compiled once per mode: -DPT_INST_MODE=1..7 (Makefile).
 #include "pt_render_kernel.h"
 #include "pt_render_inst.h"
 
@@ -12,7 +12,7 @@
 hipError_t PT_INST_CAT(pt_launch_mode_, PT_INST_MODE)(const PtRenderArgs& a, int waves, bool stats, bool tex, int n_cu, hipStream_t stream,
                                                       uint32_t* grid, bool launch) {
 #if PT_INST_MODE == 3 || PT_INST_MODE == 6
-    // scenes of analytic primitives always take 3 waves per SIMD (measured: big-scene 14.2 vs 13.0 Gray/s at 3 vs 4)
+    // the mesh-free FLAT / HIER kernels exist for 3 waves per SIMD only (round 1: big-scene 14.2 vs 13.0 Gray/s at 3 vs 4)
     (void)waves;
     return pt_dispatch_variant<PT_INST_MODE, 3>(a, stats, tex, n_cu, stream, grid, launch);
 #else

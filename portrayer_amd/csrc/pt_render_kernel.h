@@ -1,14 +1,14 @@
 // The render kernel (render.rs:127-150 and everything below it) and its launcher. Included by
-// pt_render_inst.hip, which is compiled once per traversal mode (six objects built side by side).
+// pt_render_inst.hip, which is compiled once per traversal mode (seven objects built side by side).
 //
 // Kernel design (CDNA4: 64-wide wavefronts, 256 CUs in 8 XCDs, 160 KB LDS per CU, no matrix cores involved -
 // there is no dense contraction on this path):
-//  * persistent wavefronts: the grid is what is resident on the chip. A wavefront takes work ITEMS - 64 / K
-//    neighbouring pixels of an 8x8 tile x K samples of one 8-sample chunk, K = 8 from SAMPLES >= 8 on - from a
-//    private batch it refills with ONE atomicAdd on the launch's counter (guided batch sizes). All 64 lanes
-//    start their samples together and the item ends when the last lane has finished: at any time the
-//    wavefront walks the trees with rays of ONE kind (primary, shadow to light 0, ...) through one 4x2-pixel
-//    window, which is what keeps its lanes in step inside the walk (profiles/r02/notes.md).
+//  * persistent wavefronts: the grid is what is resident on the chip. A wavefront takes work ITEMS - P neighbouring
+//    pixels of an 8x8 tile x C consecutive 8-sample chunks x K samples of a chunk, P C K = 64 (SAMPLES = 64: all 64
+//    samples of ONE pixel) - from a private batch it refills with ONE atomicAdd on the launch's counter (guided batch
+//    sizes). All 64 lanes start their samples together and the item ends when the last lane has finished: at any
+//    time the wavefront walks the trees with rays of ONE kind (primary, shadow to light 0, ...) through one pixel
+//    (or a compact window of a few), which is what keeps its lanes in step inside the walk (profiles/r02/notes.md).
 //  * one traversal loop per wavefront for all ray kinds: pt_lane_advance() turns whatever the lane traced
 //    last into its next ray, so secondary rays re-enter the same loop instead of recursing.
 //  * per-lane LDS columns: the traversal stack (32-bit words, overflowing to HBM beyond the LDS part) and
@@ -28,8 +28,8 @@
 #define PT_WORK_BATCH_MAX 32  // most work items (64 lanes each) a wavefront takes from the global counter at a time
 #endif
 // Waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument) is a
-// template parameter of the render kernel: 3 (168 VGPRs) where shading weighs in, 4 (128 VGPRs, more
-// spills, more latency hiding) where the tree walk dominates - chosen per scene in pt_scene_upload.
+// template parameter of the render kernel: 3 (168 VGPRs) is what pt_scene_upload selects for every scene;
+// 4 (128 VGPRs, more spills) measured slower everywhere with this kernel and stays as PORTRAYER_WAVES=4.
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 0  // experiments: force one value for every scene
 #endif

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fuzz parity run (not collected by pytest; run on the GPU box):
-   python tests/fuzz_gpu_parity.py <first seed> <count> [width height]
+   python tests/fuzz_gpu_parity.py <first seed> <count> [width height [samples]]
 Random scenes (tests/test_gpu_render_parity.random_scene) with extreme scales / near-degenerate
 transforms mixed in, and textured scenes; FLAT, KD and HIER, GPU vs oracle: reports every pixel that differs."""
 import sys
@@ -47,6 +47,7 @@ def extreme_scene(seed):
 def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
     w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (128, 96)
+    samples = int(sys.argv[5]) if len(sys.argv) > 5 else 2  # 2: 32 pixels x 2 samples per wavefront; 32: 2 pixels x 4 chunks x 8; 64: one pixel
     bad_total = 0
     tex_edge = 0
     for seed in range(first, first + count):
@@ -57,8 +58,8 @@ def main():
             hs = host_glue.host_scene(scene)
             for mode, tr, om in (("flat", H.TRAVERSE_FLAT, O.MODE_FLAT), ("kd", H.TRAVERSE_KD, O.MODE_KD), ("hier", H.TRAVERSE_HIER, O.MODE_HIER)):
                 r = host.Renderer(hs, tr, kd_depth=8)
-                rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=2, seed=seed, sample_mode=H.SAMPLE_RNG, stats=True)
-                ref = O.render(ps, cam, w, h, samples=2, seed=seed, jitter=O.JITTER_RNG, mode=om, kd_depth=8)
+                rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=samples, seed=seed, sample_mode=H.SAMPLE_RNG, stats=True)
+                ref = O.render(ps, cam, w, h, samples=samples, seed=seed, jitter=O.JITTER_RNG, mode=om, kd_depth=8)
                 bad = (rgb != ref.rgb).any(axis=2)
                 if kind == "textured" and bad.sum() <= 2:  # sphere uv goes through atan2 / acos: a last-bit difference may move a sample across a texel edge
                     tex_edge += int(bad.sum()); bad[:] = False
@@ -68,7 +69,7 @@ def main():
                     print(f"MISMATCH seed {seed} {kind} {mode}: {int(bad.sum())} pixels, rays_equal={rays_equal}, first {np.argwhere(bad)[:4].tolist()}, "
                           f"kd_plane_miss gpu {st['kd_plane_miss']} oracle {ref.stats['kd_plane_miss']}", flush=True)
                 r.close()
-    print(f"fuzz done: seeds {first}..{first + count - 1}, {bad_total} differing pixels in total ({tex_edge} texel-edge pixels in textured scenes tolerated)")
+    print(f"fuzz done: seeds {first}..{first + count - 1} ({9 * count} renders, {w}x{h}x{samples}), {bad_total} differing pixels in total ({tex_edge} texel-edge pixels in textured scenes tolerated)")
 
 
 if __name__ == "__main__":

@@ -152,6 +152,37 @@ def test_node_render_equals_single_context(oracle, H, ranks):
     lib.pt_node_destroy(node)
 
 
+def test_node_gather_through_rccl_with_one_rank(H, monkeypatch):
+    """The RCCL leg of pt_node_render (dlopen of librccl, ncclCommInitAll, ncclGather inside a group, untile of what the
+    gather delivered) as far as a 1-GPU box can run it: a communicator of ONE rank (PORTRAYER_NODE_RCCL=1 - without it a
+    single-GPU node skips RCCL). The gather between separate GPUs stays unexecuted here."""
+    import device_glue
+    from example_scenes import EXAMPLES
+    scene, cam, _ = EXAMPLES["macho-cows"]()
+    ds = device_glue.DeviceScene(scene, H.TRAVERSE_FLAT)
+    lib = H.lib()
+    w, h = 131, 77
+    bg = default_background(w, h)
+    ctx = H.Context()
+    ds.upload(ctx)
+    one, _, _ = device_glue.render(ctx, cam, w, h, samples=3, seed=5, sample_mode=H.SAMPLE_RNG)
+    ctx.close()
+    monkeypatch.setenv("PORTRAYER_NODE_RCCL", "1")
+    node = C.c_void_p()
+    devs = (C.c_int32 * 1)(0)
+    assert lib.pt_node_create(1, devs, C.byref(node)) == 0
+    assert lib.pt_node_ranks(node) == 1 and lib.pt_node_uses_rccl(node) == 1
+    assert lib.pt_node_scene_upload(node, C.byref(ds.struct), H.TRAVERSE_FLAT, None) == 0, lib.pt_node_last_error(node)
+    camera = device_glue.camera_struct(cam, w, h)
+    for _ in range(2):  # twice: buffers and communicator are reused
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        p = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), 3, 5, H.SAMPLE_RNG, 1, 0, 1, 1)
+        rc = lib.pt_node_render(node, C.byref(camera), bg.ctypes.data_as(H._dp), C.byref(p), img.ctypes.data_as(H._u8p), None)
+        assert rc == 0, lib.pt_node_last_error(node)
+        assert np.array_equal(img, one)
+    lib.pt_node_destroy(node)
+
+
 def test_host_renderer_on_a_node(host, H, monkeypatch):
     """PORTRAYER_DEVICES puts detail::Renderer (what Image::render builds) on a node: same picture."""
     sc = host.Scene.example("macho-cows", assets=ASSETS)

@@ -359,8 +359,8 @@ def test_hierarchical_traversal_random_scenes(oracle, host, H, seed):
 
 @pytest.mark.parametrize("name,size", [("big-mesh", (96, 54)), ("big-soup", (32, 18))])
 def test_hierarchical_traversal_large_synthetic_scene(oracle, host, H, name, size):
-    """1.25 M (instanced) triangles: the hierarchical kernel's 4-waves-per-SIMD instantiation (chosen for mesh-heavy scenes)
-    and, for big-soup, a device-built triangle tree under it."""
+    """1.25 M (instanced) triangles under the hierarchical kernel: four-child trees deep enough to leave the LDS part of the
+    traversal stack and, for big-soup, a device-built triangle tree."""
     from example_scenes import SYNTHETIC
     scene, cam, _ = SYNTHETIC[name](6)
     w, h = size
@@ -399,6 +399,30 @@ def test_device_built_trees_give_the_same_image(host, H, monkeypatch, name):
     assert np.array_equal(out["host"][1], out["device"][1])
     for k in ("primary", "shadow", "reflect", "refract", "hits"):
         assert out["host"][2][k] == out["device"][2][k], k
+
+
+@pytest.mark.parametrize("name,mode", [("macho-cows", "flat"), ("macho-cows", "kd"), ("entering-the-mirror-dimension", "hier"), ("big-scene", "kd"), ("big-scene", "flat")])
+def test_traversal_stack_beyond_lds_gives_the_same_image(host, H, monkeypatch, name, mode):
+    """The traversal stack is a per-lane LDS column with the entries beyond it in HBM (PtStackSpill). Small scenes never
+    leave the LDS part; PORTRAYER_LDS_STACK=1 keeps ONE entry in LDS, so nearly every push and pop of the walk (32-bit node
+    references and, in KD mode, the two halves of the f64 range start) goes through the HBM part."""
+    scene = host.Scene.example(name)
+    tr = {"flat": H.TRAVERSE_FLAT, "kd": H.TRAVERSE_KD, "hier": H.TRAVERSE_HIER}[mode]
+    w, h = 240, 135
+    out = {}
+    for lds in (None, "1"):
+        if lds:
+            monkeypatch.setenv("PORTRAYER_LDS_STACK", lds)
+        r = host.Renderer(scene, tr)
+        rgb, linear, st = r.render(scene.camera, w, h, default_background(w, h), samples=3, seed=3, sample_mode=H.SAMPLE_RNG, stats=True)
+        plain, _, _ = r.render(scene.camera, w, h, default_background(w, h), samples=3, seed=3, sample_mode=H.SAMPLE_RNG)
+        assert np.array_equal(plain, rgb) and st["stack_overflow"] == 0
+        out[lds] = (rgb, linear, st)
+        r.close()
+    assert np.array_equal(out[None][0], out["1"][0])
+    assert np.array_equal(out[None][1], out["1"][1])
+    for k in ("primary", "shadow", "reflect", "refract", "hits", "n_inner", "n_analytic", "n_tri"):
+        assert out[None][2][k] == out["1"][2][k], k
 
 
 def test_device_build_of_a_large_mesh_matches_oracle(oracle, host, H, monkeypatch):

@@ -209,9 +209,9 @@ def test_transmission_refraction_matches_oracle(oracle, host, H, mode):
 @pytest.mark.parametrize("scene_name,mode", [("textured-1", "flat"), ("textured-1", "kd"), ("transmission-refraction", "flat"),
                                              ("transmission-refraction", "hier"), ("water-glass", "hier")])
 def test_four_wave_instantiations_of_small_scenes(oracle, host, H, monkeypatch, scene_name, mode):
-    """The render kernel is compiled for 3 and for 4 waves per SIMD and pt_scene_upload picks 4 only for mesh-heavy scenes
-    or large k-d trees, so on small scenes the 4-wave instantiations (textured, KDMesh, hierarchical with meshes, ...) never
-    run on their own. PORTRAYER_WAVES=4 forces them; results must not depend on the register budget."""
+    """The render kernel is also compiled for 4 waves per SIMD (128 VGPRs); pt_scene_upload never picks that build any more
+    (3 waves measured faster on every workload, profiles/r02/notes.md), so it only runs when PORTRAYER_WAVES=4 forces it.
+    Results must not depend on the register budget."""
     from example_scenes import TEXTURED_EXAMPLES
     from scene_dsl import default_background
     monkeypatch.setenv("PORTRAYER_WAVES", "4")
