@@ -132,14 +132,14 @@ struct pt_context {
     int n_cu = 0;
     std::string err;
     PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh4, bvh_items, kd, kd_items;
-    PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, mkd, mkd_items;
+    PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, texview, mkd, mkd_items;
     PtBuf node_box, kd_box, mkd_box, mkd_item_box;
     PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank;  // PT_TRAVERSE_HIER: the scene graph
     PtBuf spill, stack_spill, accum, bg, rgb, linear, misc;  // misc: work counter + overflow flag (8 B), PtCounters at +256
     bool needs_spill = false;  // some material is reflective (recursion frames) or the scene has more than 32 lights
+    bool spawns = false;       // some material is reflective: hits spawn rays, so the cost of a pixel varies by orders of magnitude
     PtSceneView view;
     bool have_scene = false;
-    int waves = 3;  // occupancy variant of the render kernel for this scene (pt_dispatch)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool pending = false;
     bool pending_stats = false;
@@ -201,7 +201,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank};
+                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -604,7 +604,8 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         return rc;
     std::vector<double> mats(s->materials, s->materials + 10 * (size_t)s->n_materials);
     c->needs_spill = s->n_lights > PT_LIGHT_ROUND;
-    for (uint32_t m = 0; m < s->n_materials; m++) if (mats[10 * (size_t)m + 7] > 0.0) c->needs_spill = true;  // material.rs:216: reflectivity > 0 spawns children
+    c->spawns = false;
+    for (uint32_t m = 0; m < s->n_materials; m++) if (mats[10 * (size_t)m + 7] > 0.0) c->needs_spill = c->spawns = true;  // material.rs:216: reflectivity > 0 spawns children
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
     if ((rc = pt_upload(c, c->materials, mats)) || (rc = pt_upload(c, c->lights, lights))) return rc;
 
@@ -692,13 +693,6 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
         v.chain_off = (const uint32_t*)c->chain_off.p; v.chain = (const uint32_t*)c->chain.p; v.dfs_rank = (const uint32_t*)c->dfs_rank.p;
     }
-    // Waves per SIMD the launch is compiled for: 3 (168 VGPRs). Round 1 picked 4 (128 VGPRs, more spills, more latency
-    // hiding) for mesh-heavy scenes and large k-d trees; with a wavefront's rays confined to one 4x2-pixel window the walk
-    // waits less and the spills of the 128-register build cost more than the fourth wave hides (profiles/r02/notes.md:
-    // big-soup 3.24 vs 3.13 Gray/s, big-mesh 3.69 vs 3.67, cows 12.0 vs 10.7, mirror 14.5 vs 13.2, big-scene KD 7.2 vs 7.1).
-    // The 4-wave instantiations stay selectable (PORTRAYER_WAVES=4) and tested.
-    c->waves = 3;
-    if (const char* e = getenv("PORTRAYER_WAVES")) c->waves = atoi(e) == 4 ? 4 : 3;
     // a level of the four-child walk pushes up to three pending children and covers two levels of the two-child tree
     auto wide = [](int depth2) { return 3 * ((depth2 + 1) / 2); };
     int below = std::max(wide(max_blas_depth), 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
@@ -708,6 +702,11 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     if (textured) {
         v.mat_maps = (const int32_t*)c->mat_maps.p; v.uv_trans = (const double*)c->uv_trans.p; v.tex = (const PtTexInfo*)c->tex.p;
         v.tex_rgb = (const uint8_t*)c->tex_rgb.p; v.srgb_lut = (const double*)c->srgb_lut.p; v.tri_uv = (const double*)c->tri_uv.p;
+        std::vector<PtTexView> tv(1);
+        tv[0].tex = v.tex; tv[0].tex_rgb = v.tex_rgb; tv[0].uv_trans = v.uv_trans; tv[0].tri_v = v.tri_v; tv[0].tri_uv = v.tri_uv;
+        tv[0].mat_maps = v.mat_maps;
+        if ((rc = pt_upload(c, c->texview, tv))) return rc;
+        v.texview = (const PtTexView*)c->texview.p;
     }
     lap("upload the rest");
     if (v.stack_cap > 4096) return pt_fail(c, PT_ERR_SCENE, "tree too deep for the traversal stack");
@@ -747,17 +746,17 @@ static int pt_check_params(pt_context* c, const pt_camera* cam, const pt_render_
     return PT_OK;
 }
 
-// `waves` = pt_context::waves (3 or 4 per SIMD, chosen per scene in pt_scene_upload).
-static hipError_t pt_dispatch(const PtRenderArgs& a, int waves, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
+// a.park_slots (0 / 1) selects the instantiation without / with a parked recursion frame in LDS.
+static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
     const bool tex = a.scene.mat_maps != nullptr;
     switch (a.scene.mode) {
-    case PT_MODE_KD: return pt_launch_mode_2(a, waves, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_FLAT_NOMESH: return pt_launch_mode_3(a, waves, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_FLAT_KDMESH: return pt_launch_mode_4(a, waves, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_HIER: return pt_launch_mode_5(a, waves, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, waves, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, waves, stats, tex, n_cu, stream, grid, launch);
-    default: return pt_launch_mode_1(a, waves, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_KD: return pt_launch_mode_2(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_FLAT_NOMESH: return pt_launch_mode_3(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_FLAT_KDMESH: return pt_launch_mode_4(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER: return pt_launch_mode_5(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
+    default: return pt_launch_mode_1(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
     }
 }
 
@@ -794,19 +793,38 @@ static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_par
 }
 
 static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStream_t stream) {
-    // LDS per block = traversal stack (as much of it as leaves room for `waves` blocks per CU) + the shaded hit's frame;
+    // LDS per block = traversal stack (as much of it as leaves room for three blocks per CU) + the shaded hit's frame (+ a parked one);
     // deeper stack entries live in HBM (PtStackSpill).
     if (getenv("PORTRAYER_NO_TEX")) a.scene.mat_maps = nullptr;  // experiment: the untextured kernel on a textured scene (wrong picture, timing only)
     const bool tex = a.scene.mat_maps != nullptr;
-    const size_t frame_bytes = (size_t)(tex ? PT_LDS_FRAME_F64_TEX : PT_LDS_FRAME_F64) * PT_BLOCK * 8;
-    const size_t block_budget = c->waves == 4 ? 39 * 1024 : 52 * 1024;  // 4 x 39 KB / 3 x 52 KB of the CU's 160 KB
-    int lds_cap = (int)((block_budget - frame_bytes) / (PT_BLOCK * 4));
+    // parked recursion frames kept in LDS (pt_shade.h): only scenes that park frames at all have any
+    a.park_slots = 1;
+    if (const char* e = getenv("PORTRAYER_PARK")) a.park_slots = atoi(e) > 0 ? 1 : 0;  // 0: every parked frame in HBM (tests, measurements)
+    if (!c->spawns) a.park_slots = 0;
+    size_t block_budget = 52 * 1024;  // 3 x 52 KB of the CU's 160 KB
+    if (const char* e = getenv("PORTRAYER_LDS_BUDGET_KB")) block_budget = (size_t)std::max(16, std::min(160, atoi(e))) * 1024;  // experiment: 80 = two blocks per CU
+    const size_t frame_bytes = (size_t)(PT_LDS_FRAME_F64 + a.park_slots * PT_PARK_F64) * PT_BLOCK * 8;
+    int lds_cap = block_budget > frame_bytes ? (int)((block_budget - frame_bytes) / (PT_BLOCK * 4)) : 0;
+    lds_cap = std::max(lds_cap, 2);
     if (const char* e = getenv("PORTRAYER_LDS_STACK")) lds_cap = std::max(1, atoi(e));  // experiments / tests of the overflow path
     a.stack_lds_cap = std::min(lds_cap, a.scene.stack_cap);
     uint32_t grid = 0;
-    PT_HIP(c, pt_dispatch(a, c->waves, stats, c->n_cu, stream, &grid, false));
+    PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
     a.work_div = std::max<uint32_t>(grid * (PT_BLOCK / 64) * 8u, 1u);  // batch = remaining items / (8 x resident wavefronts)
+    // Hand-out order of the work items. Scenes whose hits can spawn rays (reflective / refractive materials) have items that cost
+    // hundreds of times the average, clustered where the glass is: in image order a wavefront's batch of consecutive items is all
+    // heavy or all light, and the heavy region may come last (transmission-refraction: wavefronts resident 47 % of the launch,
+    // 5.2 Gray/s). Position q -> item (q * stride) mod n with stride ~ 0.618 n, coprime to n, makes every batch a sample of the
+    // whole image: 10.2 Gray/s. Scenes without such materials keep the image order (neighbouring items share tree nodes: 1-3 %).
+    a.item_stride = 1;
+    {
+        const char* e = getenv("PORTRAYER_ITEM_STRIDE");  // "golden", a number, or 1 = image order
+        const bool golden = e ? strcmp(e, "golden") == 0 : c->spawns;
+        uint64_t st = golden ? (uint64_t)((double)a.n_items * 0.6180339887498949) : (e ? (uint64_t)atoll(e) : 1u);
+        auto gcd = [](uint64_t x, uint64_t y) { while (y) { uint64_t t = x % y; x = y; y = t; } return x; };
+        if (a.n_items > 2 && st != 1) { st = st % a.n_items; if (st < 1) st = 1; while (gcd(st, a.n_items) != 1) st++; a.item_stride = (uint32_t)st; }
+    }
     int rc;
     const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_STRIDE * sizeof(double) : 16;
     if ((rc = pt_reserve(c, c->spill, spill_bytes))) return rc;
@@ -822,7 +840,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters), stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
     if (a.n_items) {
-        PT_HIP(c, pt_dispatch(a, c->waves, stats, c->n_cu, stream, &grid, true));
+        PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, true));
         hipLaunchKernelGGL(pt_finish_kernel, dim3((a.n_slots + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, stream, a);
         PT_HIP(c, hipGetLastError());
     }

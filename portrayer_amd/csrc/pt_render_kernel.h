@@ -27,12 +27,13 @@
 #ifndef PT_WORK_BATCH_MAX
 #define PT_WORK_BATCH_MAX 32  // most work items (64 lanes each) a wavefront takes from the global counter at a time
 #endif
-// Waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument) is a
-// template parameter of the render kernel: 3 (168 VGPRs) is what pt_scene_upload selects for every scene;
-// 4 (128 VGPRs, more spills) measured slower everywhere with this kernel and stays as PORTRAYER_WAVES=4.
+// Waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument): 3 (168 VGPRs). 4 (128 VGPRs,
+// more spills) measured slower on every workload with this kernel (profiles/r02/notes.md) and is no longer built.
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 0  // experiments: force one value for every scene
+#define PT_MIN_WAVES 3  // experiments: -DPT_MIN_WAVES=2 / 4
 #endif
+// PARK (template parameter): 1 = the youngest parked recursion frame of a lane stays in LDS (scenes with reflective
+// materials), 0 = scenes whose hits never spawn rays: the code and the lane state for it are compiled out.
 
 __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCounters& c) {
     const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&c);
@@ -41,13 +42,13 @@ __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCount
         if (s[i]) atomicAdd(d + i, s[i]);
 }
 
-// LDS of one block: [stack_lds_cap x PT_BLOCK words of traversal stack][frame doubles x PT_BLOCK]
-__host__ __device__ inline size_t pt_render_lds_bytes(int stack_lds_cap, bool tex) {
-    return (size_t)stack_lds_cap * PT_BLOCK * 4 + (size_t)(tex ? PT_LDS_FRAME_F64_TEX : PT_LDS_FRAME_F64) * PT_BLOCK * 8;
+// LDS of one block: [stack_lds_cap x PT_BLOCK words of traversal stack][hit-frame doubles x PT_BLOCK][park_slots x 12 doubles x PT_BLOCK]
+__host__ __device__ inline size_t pt_render_lds_bytes(int stack_lds_cap, bool tex, int park_slots) {
+    return (size_t)stack_lds_cap * PT_BLOCK * 4 + (size_t)(PT_LDS_FRAME_F64 + park_slots * PT_PARK_F64) * PT_BLOCK * 8;
 }
 
-template <int MODE, bool STATS, bool TEX, int WAVES>
-__global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES) pt_render_kernel(PtRenderArgs a) {
+template <int MODE, bool STATS, bool TEX, int PARK>
+__global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRenderArgs a) {
     extern __shared__ uint32_t pt_lds[];
     const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
     stk.overflow = a.overflow_flag;
     PtFrameRef fr;
     fr.lds = reinterpret_cast<double*>(pt_lds + (size_t)a.stack_lds_cap * PT_BLOCK) + threadIdx.x;
+    fr.park = fr.lds + (size_t)PT_LDS_FRAME_F64 * PT_FRAME_STRIDE;
     fr.spill = a.spill + (size_t)lane_global * (PT_SPILL_DEPTHS * PT_SPILL_STRIDE);
     fr.n_lanes = a.n_lanes;
 
@@ -67,11 +69,15 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
     if (STATS) memset(&cnt, 0, sizeof cnt);
     PtLane L;
     L.stage = PT_ST_DONE; L.has_ray = false; L.ray_any = false;
-    L.x = L.y = L.sample = L.light = L.draw = L.draw0 = L.occluded = 0; L.depth = 0;
+    L.x = L.y = L.sample = L.light = L.draw = L.draw0 = L.occluded = 0; L.depth = 0; L.lo = 0;
     L.ray.o = L.ray.d = pt_v3(0.0, 0.0, 0.0);
     PtHit hit;
     hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
     unsigned q_next = 0, q_end = 0, q_seen = 0;  // this wavefront's private batch of items (wave-uniform); highest item index seen handed out
+#ifdef PT_TIMELINE  // profiles/timeline.sh: when wavefronts start and end, and how long the longest item takes (100 MHz ticks)
+    const unsigned long long tl_start = wall_clock64();
+    unsigned long long tl_item_max = 0;
+#endif
 
     for (;;) {
         // Next item of the wavefront's private batch; ONE atomicAdd per batch on the launch's counter (a device-scope
@@ -86,8 +92,12 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             q_next = base; q_end = base + take; q_seen = q_end;
         }
-        const unsigned w = q_next++;
-        if (w >= a.n_items) break;
+        const unsigned q = q_next++;
+        if (q >= a.n_items) break;
+        const unsigned w = a.item_stride == 1u ? q : (unsigned)(((unsigned long long)q * a.item_stride) % a.n_items);
+#ifdef PT_TIMELINE
+        const unsigned long long tl_item = wall_clock64();
+#endif
         PtItemLane it;
         const bool mine = pt_item_lane(a, w, lane, &it, &L.x, &L.y);
         L.sample = it.sample;
@@ -102,7 +112,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
 #ifdef PT_CYCLES
             const unsigned long long cyc_a = __builtin_readcyclecounter();
 #endif
-            if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH>(a, L, hit, fr, &cnt);
+            if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH, PARK>(a, L, hit, fr, &cnt);
 #ifdef PT_CYCLES
             const unsigned long long cyc_b = __builtin_readcyclecounter();
 #endif
@@ -134,24 +144,38 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES ? PT_MIN_WAVES : WAVES)
             o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef PT_TIMELINE
+        { const unsigned long long d = wall_clock64() - tl_item; if (d > tl_item_max) tl_item_max = d; }
+#endif
     }
+#ifdef PT_TIMELINE
+    if (STATS && lane == 0) {
+        const unsigned long long tl_end = wall_clock64();
+        cnt.diag[0] = tl_end - tl_start; cnt.diag[1] = 1;                       // summed: wavefront lifetimes, wavefronts
+        atomicMax(&a.counters->diag[2], tl_item_max);                             // longest item
+        atomicMax(&a.counters->diag[4], ~tl_start);                               // ~(earliest start)
+        atomicMax(&a.counters->diag[5], tl_end);                                  // latest end
+        cnt.diag[2] = cnt.diag[4] = cnt.diag[5] = 0;
+        // lifetimes in eighths of ... no kernel-wide clock is known here: the host divides
+    }
+#endif
     if (STATS) pt_flush_counters(a.counters, cnt);
 }
 
 // Launch (or, with launch = false, only size) one instantiation. The grid is what is resident: blocks per CU from
 // the occupancy query for this kernel with its LDS.
-template <int MODE, bool STATS, bool TEX, int WAVES>
+template <int MODE, bool STATS, bool TEX, int PARK>
 static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
-    size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX);
+    size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, PARK);
     static size_t lds_allowed = 64 * 1024;  // per instantiation: raised once, not on every launch
     hipError_t e;
     if (lds > lds_allowed) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, PARK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_allowed = lds;
     }
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX, WAVES>, PT_BLOCK, lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX, PARK>, PT_BLOCK, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     uint32_t want = (a.n_items + (PT_BLOCK / 64) - 1) / (PT_BLOCK / 64);
@@ -159,12 +183,12 @@ static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream,
     uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
     *grid_out = grid;
     if (!launch) return hipSuccess;
-    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, PARK>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int MODE, int WAVES>
+template <int MODE, int PARK>
 static hipError_t pt_dispatch_variant(const PtRenderArgs& a, bool stats, bool tex, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
-    if (tex) return stats ? pt_launch<MODE, true, true, WAVES>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true, WAVES>(a, n_cu, stream, grid, launch);
-    return stats ? pt_launch<MODE, true, false, WAVES>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false, WAVES>(a, n_cu, stream, grid, launch);
+    if (tex) return stats ? pt_launch<MODE, true, true, PARK>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true, PARK>(a, n_cu, stream, grid, launch);
+    return stats ? pt_launch<MODE, true, false, PARK>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false, PARK>(a, n_cu, stream, grid, launch);
 }

@@ -71,6 +71,18 @@ struct PtTexInfo {  // one RgbImageBuffer (texture.rs:74-76) inside tex_rgb
     uint32_t width, height;
 };
 
+// What the out-of-line texture routine (pt_apply_maps) reads, behind ONE pointer: a non-inlined device function gets its
+// arguments in 32 VGPRs and everything beyond that through scratch memory, so its argument list is kept short.
+struct PtTexInfo;
+struct PtTexView {
+    const PtTexInfo* tex;
+    const uint8_t* tex_rgb;
+    const double* uv_trans;
+    const double* tri_v;
+    const double* tri_uv;
+    const int32_t* mat_maps;
+};
+
 struct PtSceneView {
     uint32_t n_nodes, n_lights;
     const double* inv;
@@ -109,6 +121,7 @@ struct PtSceneView {
     const uint8_t* tex_rgb;    // RGB8 texels of all textures
     const double* srgb_lut;    // 256 entries: (k / 255)^2.2 computed on the host (texture.rs:162-168)
     const double* tri_uv;      // n_tris x 6: texture coordinates of a, b, c (mesh.rs:30, triangle.rs:18)
+    const PtTexView* texview;  // the same pointers in device memory, for pt_apply_maps
     // KDMesh triangle trees, the reference's structure (kdtree/kdmesh.rs); items are global triangle indices
     const PtKdNode* mkd;
     const uint32_t* mkd_items;

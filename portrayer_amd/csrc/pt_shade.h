@@ -25,6 +25,10 @@
 //      slots 0-2 colour so far, 3 {material, frame stage}, 4-6 refracted direction (later: the reflected
 //      colour), 7-9 hit point (origin of the refracted ray), 10 Schlick reflectance, 11 reflectivity.
 //    Hits that spawn nothing (every hit of a scene without reflective materials) never write it.
+//    The YOUNGEST parked frame of a lane stays in LDS next to the hit frame (PARK = 1 instantiations): a frame goes
+//    to its HBM line only when a deeper hit parks too and needs the slot (frames [L.lo, L.depth) are in LDS, older
+//    ones in HBM). In a recursion tree most frames are near the leaves - the children of most parked frames hit
+//    something that spawns nothing - so many pops never leave the CU (profiles/r02/notes.md).
 //  * a finished sample's colour goes to the lane's LDS column; the lane of the pixel's first sample adds
 //    the chunk's samples in ascending order (the summation contract) and writes the chunk sum.
 #pragma once
@@ -35,8 +39,8 @@
 #define PT_SPILL_SLOTS 11
 #define PT_SPILL_STRIDE 16  // doubles per parked frame: one 128-byte line, so that a push or pop of one lane touches one line
 #define PT_SPILL_DEPTHS (PT_MAX_DEPTH + 1)  // frames at depth 0..9 can have a child in flight; depth 10 only parks a colour between rounds of > 32 lights
-#define PT_LDS_FRAME_F64 10           // P, N, D, tag
-#define PT_LDS_FRAME_F64_TEX 13       // + texel colour
+#define PT_PARK_F64 12                // a parked frame: the PT_H_* slots 0..11
+#define PT_LDS_FRAME_F64 10           // P, N, D, tag (material index + the texel's three bytes when the diffuse colour is a texel)
 // Samples of a pixel are summed in chunks of PT_SAMPLE_CHUNK (8): each chunk sequentially (ascending
 // sample index), then the chunk sums sequentially (ascending chunk index). This is the build's
 // summation contract (the reference's rayon reduce has no fixed association, render.rs:36-43); it
@@ -54,7 +58,8 @@
 
 enum { PT_JITTER_CENTRE = 0, PT_JITTER_RNG = 1 };
 enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_SHADE = 4, PT_ST_DONE = 5 };
-enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_HAVE_REFRACT = 4, PT_FS_TEXTURED = 256 };
+enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_HAVE_REFRACT = 4 };  // parked frames
+#define PT_FS_TEXEL 0x80000000u  // hit frame: bits 0..23 are the texel's R, G, B bytes; the diffuse colour is srgb_lut[] of them (texture.rs:162-168)
 #define PT_LIGHT_ROUND 32  // shadow-ray results are kept as one bit per light, 32 lights at a time
 
 struct PtRenderArgs {
@@ -81,15 +86,18 @@ struct PtRenderArgs {
     uint32_t n_lanes;
     uint32_t* stack_spill;           // traversal-stack entries beyond the LDS part, entry x n_lanes
     int32_t stack_lds_cap;           // entries per lane kept in LDS; the rest (up to scene.stack_cap) in stack_spill
+    int32_t park_slots;              // parked recursion frames per lane kept in LDS (0 or 1; selects the PARK instantiation); older ones in `spill`
     unsigned int* work_counter;
     unsigned int* overflow_flag;     // set to 1 by any lane that runs out of traversal stack
     uint32_t work_div;               // a wavefront takes (remaining items / work_div) items from work_counter at a time
+    uint32_t item_stride;            // hand-out position q -> item (q * item_stride) mod n_items; 1 = in image order
     PtCounters* counters;
 };
 
 struct PtLane {
     uint32_t x, y, sample, stage, light, draw, draw0, occluded;
     int32_t depth;
+    int32_t lo;        // parked frames of depth [lo, depth) are in LDS, those of [0, lo) in HBM
     PtRay ray;
     bool has_ray, ray_any;
 };
@@ -98,6 +106,7 @@ struct PtLane {
 struct PtFrameRef {
     double* lds;       // column in the block's LDS frame area: slot s at lds[s * PT_FRAME_STRIDE]
     double* spill;     // column in the HBM recursion stack
+    double* park;      // column in the block's LDS area for parked frames: frame k, slot s at park[(k * PT_PARK_F64 + s) * PT_FRAME_STRIDE]
     uint32_t n_lanes;
     PT_HD double& l(int slot) const { return lds[slot * PT_FRAME_STRIDE]; }
     PT_HD PtVec3 l3(int slot) const { return pt_v3(l(slot), l(slot + 1), l(slot + 2)); }
@@ -105,11 +114,31 @@ struct PtFrameRef {
     PT_HD double& h(int depth, int slot) const { return spill[depth * PT_SPILL_STRIDE + slot]; }
     PT_HD PtVec3 h3(int depth, int slot) const { return pt_v3(h(depth, slot), h(depth, slot + 1), h(depth, slot + 2)); }
     PT_HD void set_h3(int depth, int slot, PtVec3 v) const { h(depth, slot) = v.x; h(depth, slot + 1) = v.y; h(depth, slot + 2) = v.z; }
+    PT_HD double& p(int k, int slot) const { return park[(k * PT_PARK_F64 + slot) * PT_FRAME_STRIDE]; }
+    // A parked frame as 12 doubles (the PT_H_* slots), wherever it lives. The HBM line is 128-byte aligned: 16-byte accesses.
+    PT_HD void load_hbm(int depth, double* f) const {
+        const double2* q = reinterpret_cast<const double2*>(spill + depth * PT_SPILL_STRIDE);
+#pragma unroll
+        for (int i = 0; i < PT_PARK_F64 / 2; i++) { double2 v = q[i]; f[2 * i] = v.x; f[2 * i + 1] = v.y; }
+    }
+    PT_HD void store_hbm(int depth, const double* f) const {
+        double2* q = reinterpret_cast<double2*>(spill + depth * PT_SPILL_STRIDE);
+#pragma unroll
+        for (int i = 0; i < PT_PARK_F64 / 2; i++) { double2 v; v.x = f[2 * i]; v.y = f[2 * i + 1]; q[i] = v; }
+    }
+    PT_HD void load_lds(int k, double* f) const {
+#pragma unroll
+        for (int i = 0; i < PT_PARK_F64; i++) f[i] = p(k, i);
+    }
+    PT_HD void store_lds(int k, const double* f) const {
+#pragma unroll
+        for (int i = 0; i < PT_PARK_F64; i++) p(k, i) = f[i];
+    }
     static PT_HD double pack_tag(uint32_t mat, uint32_t stage) { union { double d; uint32_t u[2]; } c; c.u[0] = mat; c.u[1] = stage; return c.d; }
     static PT_HD void unpack_tag(double t, uint32_t* mat, uint32_t* stage) { union { double d; uint32_t u[2]; } c; c.d = t; *mat = c.u[0]; *stage = c.u[1]; }
 };
 // LDS frame slots
-enum { PT_L_P = 0, PT_L_N = 3, PT_L_D = 6, PT_L_TAG = 9, PT_L_KD = 10, PT_L_VALUE = 0 /* a finished sample's colour reuses P */ };
+enum { PT_L_P = 0, PT_L_N = 3, PT_L_D = 6, PT_L_TAG = 9, PT_L_VALUE = 0 /* a finished sample's colour reuses P */ };
 // HBM spill slots
 enum { PT_H_COLOR = 0, PT_H_TAG = 3, PT_H_DIR = 4, PT_H_P = 7, PT_H_SCHLICK = 10, PT_H_REFL = 11 /* the material's reflectivity: the pop needs no material fetch */ };
 
@@ -272,10 +301,30 @@ PT_HD PtVec3 pt_mat3_mul(const PtMat3& m, PtVec3 v) {  // row dot products, left
 // type / sub / local / t identify the hit (as in PT_ST_CLOSEST_DONE); p, n = its model-space point and
 // raw normal. Returns the diffuse colour (texel or *kd unchanged) and, when the material has a normal
 // map, the shading normal (NOT multiplied by the node's normal_trans: quirk Q12 of the reference).
-PT_NOINLINE void pt_apply_maps(const PtTexInfo* tex, const uint8_t* tex_rgb, const double* lut, const double* uv_trans9, const double* tri_v,
-                               const double* tri_uv, uint32_t type, uint32_t sub, double ox, double oy, double oz, double dx, double dy, double dz,
-                               double px, double py, double pz, double nx, double ny, double nz, int32_t tex_id, int32_t nmap_id,
-                               double* kd_out, double* n_out, int* has_n) {
+// Arguments and result travel in registers (29 and 13 VGPRs): a longer list or pointers to locals go through scratch memory,
+// which on a scene with 196,608 resident lanes is HBM traffic (measured on transmission-refraction: half of the launch's
+// HBM-side bytes, profiles/r02/notes.md).
+struct PtMapsOut {
+    double n[3];
+    int32_t has_n;
+    uint32_t texel;  // PT_FS_TEXEL | R | G << 8 | B << 16 when the material has a texture, else 0
+};
+#ifdef PT_MAPS_INLINE
+#define PT_MAPS_ATTR PT_HD
+#else
+#define PT_MAPS_ATTR PT_NOINLINE
+#endif
+PT_MAPS_ATTR PtMapsOut pt_apply_maps(const PtTexView* view, uint32_t mat, uint32_t type, uint32_t sub, double ox, double oy, double oz, double dx, double dy,
+                                    double dz, double px, double py, double pz, double nx, double ny, double nz) {
+    const PtTexInfo* tex = view->tex;
+    const uint8_t* tex_rgb = view->tex_rgb;
+    const double* uv_trans9 = view->uv_trans + 9 * (size_t)mat;
+    const double* tri_v = view->tri_v;
+    const double* tri_uv = view->tri_uv;
+    const int32_t tex_id = view->mat_maps[2 * mat], nmap_id = view->mat_maps[2 * mat + 1];
+    PtMapsOut out;
+    out.texel = 0;
+    out.n[0] = out.n[1] = out.n[2] = 0.0;
     PtVec3 p = pt_v3(px, py, pz), n = pt_v3(nx, ny, nz);
     double u = 0.0, v = 0.0;
     PtMat3 tbn;
@@ -326,19 +375,20 @@ PT_NOINLINE void pt_apply_maps(const PtTexInfo* tex, const uint8_t* tex_rgb, con
     // material.rs:113-117: uv_trans * (u, v, 1)
     double tu = (uv_trans9[0] * u + uv_trans9[1] * v) + uv_trans9[2] * 1.0;
     double tv2 = (uv_trans9[3] * u + uv_trans9[4] * v) + uv_trans9[5] * 1.0;
-    *has_n = 0;
+    out.has_n = 0;
     if (nmap_id >= 0) {  // texture.rs:192-221 + material.rs:126-132
         PtVec3 c = pt_texel(tex, tex_rgb, nmap_id, tu, tv2) / 255.0;
         PtVec3 norm = pt_v3(2.0 * c.x - 1.0, 2.0 * c.y - 1.0, -(2.0 * c.z - 1.0));
         PtVec3 tex_norm = pt_v3(norm.x, -norm.z, -norm.y);  // normal_to_rh * norm (a signed permutation: exact)
         PtVec3 shading = pt_mat3_mul(tbn, pt_normalized(tex_norm));
-        n_out[0] = shading.x; n_out[1] = shading.y; n_out[2] = shading.z;
-        *has_n = 1;
+        out.n[0] = shading.x; out.n[1] = shading.y; out.n[2] = shading.z;
+        out.has_n = 1;
     }
     if (tex_id >= 0) {  // texture.rs:162-168 through the host-built (k / 255)^2.2 table
         PtVec3 c = pt_texel(tex, tex_rgb, tex_id, tu, tv2);
-        kd_out[0] = lut[(int)c.x]; kd_out[1] = lut[(int)c.y]; kd_out[2] = lut[(int)c.z];
+        out.texel = PT_FS_TEXEL | (uint32_t)(int)c.x | ((uint32_t)(int)c.y << 8) | ((uint32_t)(int)c.z << 16);
     }
+    return out;
 }
 
 // Runs the lane's interpreter until it needs a ray traced (L.has_ray) or its sample is finished
@@ -349,7 +399,7 @@ PT_NOINLINE void pt_apply_maps(const PtTexInfo* tex, const uint8_t* tex_rgb, con
 #define PT_ADVANCE_ATTR PT_HD
 #endif
 // TEX = false compiles the texture / normal-map path out (scenes without mapped materials).
-template <bool STATS, bool TEX, bool HIER = false>
+template <bool STATS, bool TEX, bool HIER = false, int PARK = 0>
 PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt) {
     const PtSceneView& sc = a.scene;
     L.has_ray = false;
@@ -365,13 +415,17 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 return;
             }
             L.depth--;
+            double f[PT_PARK_F64];
+            const bool in_lds = PARK > 0 && L.depth >= L.lo;
+            if (in_lds) fr.load_lds(0, f);
+            else { fr.load_hbm(L.depth, f); if (PARK > 0) L.lo = L.depth; }  // nothing younger can be parked: the LDS slot is free
             uint32_t mat, fstage;
-            PtFrameRef::unpack_tag(fr.h(L.depth, PT_H_TAG), &mat, &fstage);
-            const double reflectivity = fr.h(L.depth, PT_H_REFL);
-            PtVec3 color = fr.h3(L.depth, PT_H_COLOR);
+            PtFrameRef::unpack_tag(f[PT_H_TAG], &mat, &fstage);
+            const double reflectivity = f[PT_H_REFL];
+            PtVec3 color = pt_v3(f[PT_H_COLOR], f[PT_H_COLOR + 1], f[PT_H_COLOR + 2]);
             if ((fstage & PT_FS_STAGE_MASK) == PT_FS_WAIT_REFRACT) {  // material.rs:305-309
-                PtVec3 reflected = fr.h3(L.depth, PT_H_DIR);
-                double schlick = fr.h(L.depth, PT_H_SCHLICK);
+                PtVec3 reflected = pt_v3(f[PT_H_DIR], f[PT_H_DIR + 1], f[PT_H_DIR + 2]);
+                double schlick = f[PT_H_SCHLICK];
                 double transmittance = 1.0 - schlick;
                 PtVec3 total = reflected * schlick + value * transmittance;
                 value = color + total * reflectivity;
@@ -385,11 +439,20 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 continue;
             }
             // the refracted ray (material.rs:286-303); its direction was worked out when the hit was shaded
-            PtVec3 refract_dir = fr.h3(L.depth, PT_H_DIR);
-            L.ray.o = fr.h3(L.depth, PT_H_P);
-            L.ray.d = refract_dir;
-            fr.set_h3(L.depth, PT_H_DIR, value);
-            fr.h(L.depth, PT_H_TAG) = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFRACT);
+            L.ray.o = pt_v3(f[PT_H_P], f[PT_H_P + 1], f[PT_H_P + 2]);
+            L.ray.d = pt_v3(f[PT_H_DIR], f[PT_H_DIR + 1], f[PT_H_DIR + 2]);
+            // the frame waits again, now for the refracted subtree, with the reflected colour in place of the direction
+            const double tag2 = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFRACT);
+            if (in_lds) {
+                fr.p(0, PT_H_DIR) = value.x; fr.p(0, PT_H_DIR + 1) = value.y; fr.p(0, PT_H_DIR + 2) = value.z;
+                fr.p(0, PT_H_TAG) = tag2;
+            } else if (PARK > 0) {  // it came from HBM and the LDS slot is free: it need not go back
+                f[PT_H_DIR] = value.x; f[PT_H_DIR + 1] = value.y; f[PT_H_DIR + 2] = value.z; f[PT_H_TAG] = tag2;
+                fr.store_lds(0, f);
+            } else {
+                fr.set_h3(L.depth, PT_H_DIR, value);
+                fr.h(L.depth, PT_H_TAG) = tag2;
+            }
             L.depth++;
             L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
             if (STATS) cnt->refract++;
@@ -407,6 +470,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             L.draw = 2;
             L.ray = pt_camera_ray(a.cam, (double)L.x + jx, (double)L.y + jy);
             L.depth = 0;
+            if (PARK > 0) L.lo = 0;
             L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
             if (STATS) cnt->primary++;
             return;
@@ -454,15 +518,10 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
             uint32_t ftag = 0;
             if (TEX && sc.mat_maps && (sc.mat_maps[2 * mat] >= 0 || sc.mat_maps[2 * mat + 1] >= 0)) {  // material.rs:109-144
-                const double* m = sc.materials + 10 * (size_t)mat;
-                double kdv[3] = {m[0], m[1], m[2]}, nv[3];
-                int has_n;
-                pt_apply_maps(sc.tex, sc.tex_rgb, sc.srgb_lut, sc.uv_trans + 9 * (size_t)mat, sc.tri_v, sc.tri_uv, type, hit.sub,
-                              local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z, p.x, p.y, p.z, n.x, n.y, n.z,
-                              sc.mat_maps[2 * mat], sc.mat_maps[2 * mat + 1], kdv, nv, &has_n);
-                if (has_n) N = pt_v3(nv[0], nv[1], nv[2]);
-                if (TEX) fr.set_l3(PT_L_KD, pt_v3(kdv[0], kdv[1], kdv[2]));
-                ftag = PT_FS_TEXTURED;
+                PtMapsOut mo = pt_apply_maps(sc.texview, mat, type, hit.sub, local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z,
+                                             p.x, p.y, p.z, n.x, n.y, n.z);
+                if (mo.has_n) N = pt_v3(mo.n[0], mo.n[1], mo.n[2]);
+                ftag = mo.texel;
             }
             fr.set_l3(PT_L_N, N);
             fr.set_l3(PT_L_D, L.ray.d);
@@ -501,7 +560,8 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             PtFrameRef::unpack_tag(fr.l(PT_L_TAG), &mat, &ftag);
             const double* m = sc.materials + 10 * (size_t)mat;
             PtVec3 ray_dir = fr.l3(PT_L_D), P = fr.l3(PT_L_P), N = fr.l3(PT_L_N);
-            PtVec3 kd = (TEX && (ftag & PT_FS_TEXTURED)) ? fr.l3(PT_L_KD) : pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
+            PtVec3 kd = pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
+            if (TEX && (ftag & PT_FS_TEXEL)) kd = pt_v3(sc.srgb_lut[ftag & 255u], sc.srgb_lut[(ftag >> 8) & 255u], sc.srgb_lut[(ftag >> 16) & 255u]);
             const uint32_t round_first = (L.light - 1u) / PT_LIGHT_ROUND * PT_LIGHT_ROUND;  // L.light > 0 here unless the scene has no light
             PtVec3 color;
             if (sc.n_lights == 0 || round_first == 0) color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * kd;  // material.rs:148
@@ -585,13 +645,25 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 returning = true;
                 continue;
             }
-            fr.set_h3(L.depth, PT_H_COLOR, color);
-            fr.h(L.depth, PT_H_TAG) = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFLECT | (have ? PT_FS_HAVE_REFRACT : 0));
-            fr.h(L.depth, PT_H_REFL) = reflectivity;
-            if (have) {
-                fr.set_h3(L.depth, PT_H_DIR, refract_dir);
-                fr.set_h3(L.depth, PT_H_P, P);
-                fr.h(L.depth, PT_H_SCHLICK) = schlick;
+            {
+                double f[PT_PARK_F64];
+                f[PT_H_COLOR] = color.x; f[PT_H_COLOR + 1] = color.y; f[PT_H_COLOR + 2] = color.z;
+                f[PT_H_TAG] = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFLECT | (have ? PT_FS_HAVE_REFRACT : 0));
+                f[PT_H_DIR] = refract_dir.x; f[PT_H_DIR + 1] = refract_dir.y; f[PT_H_DIR + 2] = refract_dir.z;
+                f[PT_H_P] = P.x; f[PT_H_P + 1] = P.y; f[PT_H_P + 2] = P.z;
+                f[PT_H_SCHLICK] = schlick;
+                f[PT_H_REFL] = reflectivity;
+                if (PARK > 0) {
+                    if (L.depth - L.lo == 1) {  // the LDS slot holds the parent's frame: that one goes to its HBM line
+                        double old[PT_PARK_F64];
+                        fr.load_lds(0, old);
+                        fr.store_hbm(L.lo, old);
+                        L.lo++;
+                    }
+                    fr.store_lds(0, f);
+                } else {
+                    fr.store_hbm(L.depth, f);
+                }
             }
             L.ray.o = P;
             L.ray.d = reflect_dir;

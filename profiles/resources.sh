@@ -14,6 +14,6 @@ for blk in t.split('remark: Function Name: ')[1:]:
     k = re.search(r'pt_render_kernelILi(\d)ELb(\d)ELb(\d)ELi(\d)', name)
     if not k: continue
     g = lambda key: re.search(key + r': (\d+)', blk).group(1)
-    print('mode %s stats %s tex %s waves %s : vgpr %3s agpr %3s vgpr-spill %3s sgpr-spill %3s scratch %4s B/lane occupancy %s' % (*k.groups(), g(' VGPRs'), g('AGPRs'), g('VGPRs Spill'), g('SGPRs Spill'), g(r'ScratchSize \[bytes/lane\]'), g(r'Occupancy \[waves/SIMD\]')))
+    print('mode %s stats %s tex %s park %s : vgpr %3s agpr %3s vgpr-spill %3s sgpr-spill %3s scratch %4s B/lane occupancy %s' % (*k.groups(), g(' VGPRs'), g('AGPRs'), g('VGPRs Spill'), g('SGPRs Spill'), g(r'ScratchSize \[bytes/lane\]'), g(r'Occupancy \[waves/SIMD\]')))
 PY
 done

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Where does hipcc spill? Compiles one mode's render kernels with -g -save-temps and lists the scratch
 loads / stores of one instantiation by source line.
-usage: spills.py [extra hipcc flags]   (env KERNEL = "MODE,STATS,TEX,WAVES", default "3,0,0,3")"""
+usage: spills.py [extra hipcc flags]   (env KERNEL = "MODE,STATS,TEX,PARK", default "3,0,0,0")"""
 import collections, os, re, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tmp = "/tmp/pt_spills"
 shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp)
-mode, stats, tex, waves = os.environ.get("KERNEL", "3,0,0,3").split(",")
+mode, stats, tex, waves = os.environ.get("KERNEL", "3,0,0,0").split(",")
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value",
        "--cuda-device-only", "-save-temps", "-g", f"-DPT_INST_MODE={mode}", *sys.argv[1:], "-c", root + "/portrayer_amd/csrc/pt_render_inst.hip", "-o", "x.o"]
 subprocess.run(cmd, cwd=tmp, stderr=subprocess.DEVNULL, timeout=900)

@@ -208,13 +208,13 @@ def test_transmission_refraction_matches_oracle(oracle, host, H, mode):
 
 @pytest.mark.parametrize("scene_name,mode", [("textured-1", "flat"), ("textured-1", "kd"), ("transmission-refraction", "flat"),
                                              ("transmission-refraction", "hier"), ("water-glass", "hier")])
-def test_four_wave_instantiations_of_small_scenes(oracle, host, H, monkeypatch, scene_name, mode):
-    """The render kernel is also compiled for 4 waves per SIMD (128 VGPRs); pt_scene_upload never picks that build any more
-    (3 waves measured faster on every workload, profiles/r02/notes.md), so it only runs when PORTRAYER_WAVES=4 forces it.
-    Results must not depend on the register budget."""
+def test_recursion_frames_all_in_hbm(oracle, host, H, monkeypatch, scene_name, mode):
+    """Scenes with reflective materials run the PARK = 1 instantiations (a lane's youngest parked recursion frame stays in
+    LDS, older ones go to HBM). PORTRAYER_PARK=0 forces the instantiations that keep every parked frame in HBM, which
+    such scenes otherwise never run; results must not depend on where a frame waits."""
     from example_scenes import TEXTURED_EXAMPLES
     from scene_dsl import default_background
-    monkeypatch.setenv("PORTRAYER_WAVES", "4")
+    monkeypatch.setenv("PORTRAYER_PARK", "0")
     scene, cam = textured_scene(1) if scene_name == "textured-1" else TEXTURED_EXAMPLES[scene_name]()[:2]
     tr, om = {"flat": (H.TRAVERSE_FLAT, oracle.MODE_FLAT), "kd": (H.TRAVERSE_KD, oracle.MODE_KD), "hier": (H.TRAVERSE_HIER, oracle.MODE_HIER)}[mode]
     w, h = 200, 112
