@@ -812,16 +812,16 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
     a.work_div = std::max<uint32_t>(grid * (PT_BLOCK / 64) * 8u, 1u);  // batch = remaining items / (8 x resident wavefronts)
-    // Hand-out order of the work items. Scenes whose hits can spawn rays (reflective / refractive materials) have items that cost
-    // hundreds of times the average, clustered where the glass is: in image order a wavefront's batch of consecutive items is all
-    // heavy or all light, and the heavy region may come last (transmission-refraction: wavefronts resident 47 % of the launch,
-    // 5.2 Gray/s). Position q -> item (q * stride) mod n with stride ~ 0.618 n, coprime to n, makes every batch a sample of the
-    // whole image: 10.2 Gray/s. Scenes without such materials keep the image order (neighbouring items share tree nodes: 1-3 %).
+    // How the work items are handed out (pt_render_kernel): batches of consecutive items from one counter, or - scenes whose
+    // hits can spawn rays, where an item in the glass costs hundreds of times its neighbour - one item at a time from
+    // interleaved queues. transmission-refraction: wavefronts resident 47 % of the launch and 5.2 Gray/s with batches, 11+ without.
+    a.batch_max = PT_WORK_BATCH_MAX;
+    if (const char* e = getenv("PORTRAYER_BATCH_MAX")) a.batch_max = (uint32_t)std::max(1, atoi(e));
+    a.fine_queues = c->spawns ? PT_FINE_QUEUES : 0;
+    if (const char* e = getenv("PORTRAYER_FINE_QUEUES")) a.fine_queues = (uint32_t)std::max(0, std::min(PT_FINE_QUEUES, atoi(e)));
     a.item_stride = 1;
-    {
-        const char* e = getenv("PORTRAYER_ITEM_STRIDE");  // "golden", a number, or 1 = image order
-        const bool golden = e ? strcmp(e, "golden") == 0 : c->spawns;
-        uint64_t st = golden ? (uint64_t)((double)a.n_items * 0.6180339887498949) : (e ? (uint64_t)atoll(e) : 1u);
+    if (const char* e = getenv("PORTRAYER_ITEM_STRIDE")) {  // experiment (batches only): position q -> item (q * stride) mod n; "golden" = 0.618 n
+        uint64_t st = strcmp(e, "golden") == 0 ? (uint64_t)((double)a.n_items * 0.6180339887498949) : (uint64_t)atoll(e);
         auto gcd = [](uint64_t x, uint64_t y) { while (y) { uint64_t t = x % y; x = y; y = t; } return x; };
         if (a.n_items > 2 && st != 1) { st = st % a.n_items; if (st < 1) st = 1; while (gcd(st, a.n_items) != 1) st++; a.item_stride = (uint32_t)st; }
     }
@@ -829,7 +829,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_STRIDE * sizeof(double) : 16;
     if ((rc = pt_reserve(c, c->spill, spill_bytes))) return rc;
     if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * (size_t)std::max(a.scene.stack_cap - a.stack_lds_cap, 0) * 4))) return rc;
-    if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters)))) return rc;
+    if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4))) return rc;
     if ((rc = pt_reserve(c, c->accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
     a.accum = (double*)c->accum.p;
     a.spill = (double*)c->spill.p;
@@ -837,7 +837,8 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.work_counter = (unsigned int*)c->misc.p;
     a.overflow_flag = (unsigned int*)c->misc.p + 1;
     a.counters = (PtCounters*)((char*)c->misc.p + 256);
-    PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters), stream));
+    a.work_queues = (unsigned int*)((char*)c->misc.p + 256 + sizeof(PtCounters));
+    PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
     if (a.n_items) {
         PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, true));

@@ -24,9 +24,6 @@
 
 #include "pt_shade.h"
 
-#ifndef PT_WORK_BATCH_MAX
-#define PT_WORK_BATCH_MAX 32  // most work items (64 lanes each) a wavefront takes from the global counter at a time
-#endif
 // Waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument): 3 (168 VGPRs). 4 (128 VGPRs,
 // more spills) measured slower on every workload with this kernel (profiles/r02/notes.md) and is no longer built.
 #ifndef PT_MIN_WAVES
@@ -74,27 +71,48 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
     PtHit hit;
     hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
     unsigned q_next = 0, q_end = 0, q_seen = 0;  // this wavefront's private batch of items (wave-uniform); highest item index seen handed out
+    if (a.fine_queues) q_next = blockIdx.x % a.fine_queues;
 #ifdef PT_TIMELINE  // profiles/timeline.sh: when wavefronts start and end, and how long the longest item takes (100 MHz ticks)
     const unsigned long long tl_start = wall_clock64();
     unsigned long long tl_item_max = 0;
 #endif
 
     for (;;) {
-        // Next item of the wavefront's private batch; ONE atomicAdd per batch on the launch's counter (a device-scope
-        // atomic round trip stalls the whole wavefront). Guided batch size: large while plenty of work remains, one item
-        // at a time near the end, so the launch's tail stays short.
-        if (q_next == q_end) {
-            unsigned remaining = a.n_items > q_seen ? a.n_items - q_seen : 0u;
-            unsigned take = remaining / a.work_div;
-            take = take > PT_WORK_BATCH_MAX ? PT_WORK_BATCH_MAX : (take < 1u ? 1u : take);
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(a.work_counter, take);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            q_next = base; q_end = base + take; q_seen = q_end;
+        unsigned w;
+        if (a.fine_queues == 0u) {
+            // Next item of the wavefront's private batch; ONE atomicAdd per batch on the launch's counter (a device-scope
+            // atomic round trip stalls the whole wavefront). Guided batch size: large while plenty of work remains, one item
+            // at a time near the end, so the launch's tail stays short.
+            if (q_next == q_end) {
+                unsigned remaining = a.n_items > q_seen ? a.n_items - q_seen : 0u;
+                unsigned take = remaining / a.work_div;
+                take = take > a.batch_max ? a.batch_max : (take < 1u ? 1u : take);
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(a.work_counter, take);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                q_next = base; q_end = base + take; q_seen = q_end;
+            }
+            const unsigned q = q_next++;
+            if (q >= a.n_items) break;
+            w = a.item_stride == 1u ? q : (unsigned)(((unsigned long long)q * a.item_stride) % a.n_items);
+        } else {
+            // Scenes whose hits spawn rays: an item in the glass costs hundreds of times one beside it, and such items come in
+            // large regions. Any batch of consecutive items may then be a batch of heavy ones (one wavefront busy for several
+            // launch durations), so items are taken ONE at a time, in image order - every wavefront reaches the heavy region
+            // at the same time and the region is shared item by item. To keep 3072 wavefronts off a single counter there are N
+            // queues, queue g holding the items g, g + N, g + 2N ...; a wavefront starts at the queue of its block and moves on
+            // to the next one when a queue is empty (q_next = its queue, q_end = empty queues seen in a row).
+            for (;;) {
+                unsigned idx = 0;
+                if (lane == 0) idx = atomicAdd(a.work_queues + q_next * PT_QUEUE_STRIDE, 1u);
+                idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+                const unsigned long long pos = (unsigned long long)idx * a.fine_queues + q_next;
+                if (pos < a.n_items) { w = (unsigned)pos; q_end = 0; break; }
+                q_next = q_next + 1u == a.fine_queues ? 0u : q_next + 1u;
+                if (++q_end == a.fine_queues) { w = 0xFFFFFFFFu; break; }
+            }
+            if (w == 0xFFFFFFFFu) break;
         }
-        const unsigned q = q_next++;
-        if (q >= a.n_items) break;
-        const unsigned w = a.item_stride == 1u ? q : (unsigned)(((unsigned long long)q * a.item_stride) % a.n_items);
 #ifdef PT_TIMELINE
         const unsigned long long tl_item = wall_clock64();
 #endif

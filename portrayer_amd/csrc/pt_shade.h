@@ -56,6 +56,12 @@
 #define PT_FENCE
 #endif
 
+#define PT_QUEUE_STRIDE 32  // words between two queue counters: one 128-byte line each
+#define PT_FINE_QUEUES 64
+#ifndef PT_WORK_BATCH_MAX
+#define PT_WORK_BATCH_MAX 32  // most work items (64 lanes each) a wavefront takes from the global counter at a time (PtRenderArgs::batch_max)
+#endif
+
 enum { PT_JITTER_CENTRE = 0, PT_JITTER_RNG = 1 };
 enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_SHADE = 4, PT_ST_DONE = 5 };
 enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_HAVE_REFRACT = 4 };  // parked frames
@@ -90,6 +96,9 @@ struct PtRenderArgs {
     unsigned int* work_counter;
     unsigned int* overflow_flag;     // set to 1 by any lane that runs out of traversal stack
     uint32_t work_div;               // a wavefront takes (remaining items / work_div) items from work_counter at a time
+    uint32_t batch_max;              // most items a wavefront takes at a time
+    uint32_t fine_queues;            // 0: batches from work_counter. N > 0: one item at a time from N interleaved queues (work_queues), see pt_render_kernel
+    unsigned int* work_queues;       // N counters, PT_QUEUE_STRIDE words apart
     uint32_t item_stride;            // hand-out position q -> item (q * item_stride) mod n_items; 1 = in image order
     PtCounters* counters;
 };
