@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
     if (STATS) memset(&cnt, 0, sizeof cnt);
     PtLane L;
     L.stage = PT_ST_DONE; L.has_ray = false; L.ray_any = false;
-    L.x = L.y = L.sample = L.light = L.draw = L.draw0 = L.occluded = 0; L.depth = 0; L.lo = 0;
+    L.item = 0; L.x = L.y = 0; L.light = L.draw = L.draw0 = L.occluded = 0; L.depth = 0; L.lo = 0;
     L.ray.o = L.ray.d = pt_v3(0.0, 0.0, 0.0);
     PtHit hit;
     hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
@@ -116,10 +116,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
 #ifdef PT_TIMELINE
         const unsigned long long tl_item = wall_clock64();
 #endif
-        PtItemLane it;
-        const bool mine = pt_item_lane(a, w, lane, &it, &L.x, &L.y);
-        L.sample = it.sample;
-        L.stage = mine ? PT_ST_NEW_SAMPLE : PT_ST_DONE;
+        {
+            PtItemLane it0;
+            uint32_t x0, y0;
+            const bool mine0 = pt_item_lane(a, w, lane, &it0, &x0, &y0);
+            L.item = w;
+            L.x = x0; L.y = y0;
+            L.stage = mine0 ? PT_ST_NEW_SAMPLE : PT_ST_DONE;
+        }
         L.has_ray = false;
         for (;;) {
             const bool active = L.stage != PT_ST_DONE;
@@ -152,6 +156,16 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // The lane's place in the item is worked out again (a dozen integer operations on the wave-uniform item index) rather
+        // than kept across the loop above, where it would be four registers spilled to scratch memory by every wavefront for
+        // every item - 2 GB of HBM writes per frame. The empty asm keeps the compiler from reusing the first computation.
+        unsigned w_again = w;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(w_again));
+#endif
+        PtItemLane it;
+        uint32_t x_again, y_again;
+        const bool mine = pt_item_lane(a, w_again, lane, &it, &x_again, &y_again);
         if (mine && it.first) {
             PtVec3 sum = fr.l3(PT_L_VALUE);
             for (uint32_t k = 1; k < it.count; k++) {

@@ -59,7 +59,7 @@
 #define PT_QUEUE_STRIDE 32  // words between two queue counters: one 128-byte line each
 #define PT_FINE_QUEUES 64
 #ifndef PT_WORK_BATCH_MAX
-#define PT_WORK_BATCH_MAX 32  // most work items (64 lanes each) a wavefront takes from the global counter at a time (PtRenderArgs::batch_max)
+#define PT_WORK_BATCH_MAX 8  // most work items (64 lanes each) a wavefront takes from the global counter at a time (PtRenderArgs::batch_max): 32 -> 8 costs big-scene 0.4 % and gives the 1.25 M-triangle scenes 4-7 % (profiles/r02/notes.md)
 #endif
 
 enum { PT_JITTER_CENTRE = 0, PT_JITTER_RNG = 1 };
@@ -104,7 +104,9 @@ struct PtRenderArgs {
 };
 
 struct PtLane {
-    uint32_t x, y, sample, stage, light, draw, draw0, occluded;
+    uint32_t item;     // the wavefront's work item (wave-uniform)
+    uint32_t x, y;     // its pixel; its sample index is worked out from `item` where it is needed (pt_lane_sample)
+    uint32_t stage, light, draw, draw0, occluded;
     int32_t depth;
     int32_t lo;        // parked frames of depth [lo, depth) are in LDS, those of [0, lo) in HBM
     PtRay ray;
@@ -197,6 +199,24 @@ PT_HD bool pt_item_lane(const PtRenderArgs& a, uint32_t w, uint32_t lane, PtItem
     return pt_slot_to_pixel(a, it->slot, x, y) && si < it->count;
 }
 
+// The lane's sample index, worked out from the wave-uniform item index where it is needed (the jitter draws at the start of
+// the sample, area-light and glossy draws) instead of being carried through every tree walk in a register that hipcc then
+// spills at the start of every item (measured: 2.3 -> 0.7 GB of scratch writes per 1920x1080x64 frame, +0.5-2 % on most
+// workloads; doing the same for x and y cost big-scene 3 %). The empty asm stops the compiler from hoisting the computation
+// out of the sample loop and keeping the result live after all.
+PT_HD uint32_t pt_lane_sample(const PtRenderArgs& a, uint32_t item) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(item));
+    const uint32_t lane = threadIdx.x & 63u;
+#else
+    const uint32_t lane = 0;
+#endif
+    PtItemLane it;
+    uint32_t x, y;
+    pt_item_lane(a, item, lane, &it, &x, &y);
+    return it.sample;
+}
+
 PT_HD PtVec3 pt_background(const PtRenderArgs& a, uint32_t x, uint32_t y) {  // render.rs:31-34
     const double* b = a.background_rows ? a.background + 3 * (size_t)y : a.background + 3 * ((size_t)y * a.width + x);
     return pt_v3(b[0], b[1], b[2]);
@@ -278,9 +298,10 @@ PT_HD PtVec3 pt_light_position(const PtRenderArgs& a, const PtLane& L, const dou
     bool empty = (aa.x == 0.0 && aa.y == 0.0 && aa.z == 0.0) || (ab.x == 0.0 && ab.y == 0.0 && ab.z == 0.0);  // light.rs:51-53
     *is_area = !empty;
     if (empty) return pos;
+    const uint32_t sample = pt_lane_sample(a, L.item);
     uint64_t pixel = (uint64_t)L.y * a.width + L.x;
-    double a_coord = 2.0 * pt_rng_f64(a.seed, pixel, L.sample, draw0) - 1.0;
-    double b_coord = 2.0 * pt_rng_f64(a.seed, pixel, L.sample, draw0 + 1) - 1.0;
+    double a_coord = 2.0 * pt_rng_f64(a.seed, pixel, sample, draw0) - 1.0;
+    double b_coord = 2.0 * pt_rng_f64(a.seed, pixel, sample, draw0 + 1) - 1.0;
     return pos + (aa * a_coord + ab * b_coord);
 }
 
@@ -472,9 +493,10 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             PT_FENCE;
             double jx = 0.5, jy = 0.5;
             if (a.jitter_mode == PT_JITTER_RNG) {  // render.rs:38-39: x drawn before y
+                const uint32_t sample = pt_lane_sample(a, L.item);
                 uint64_t pixel = (uint64_t)L.y * a.width + L.x;
-                jx = pt_rng_f64(a.seed, pixel, L.sample, 0);
-                jy = pt_rng_f64(a.seed, pixel, L.sample, 1);
+                jx = pt_rng_f64(a.seed, pixel, sample, 0);
+                jy = pt_rng_f64(a.seed, pixel, sample, 1);
             }
             L.draw = 2;
             L.ray = pt_camera_ray(a.cam, (double)L.x + jx, (double)L.y + jy);
@@ -615,9 +637,10 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                                  ? reflect_dir + pt_v3(0.0, 0.1, 0.0) : reflect_dir + pt_v3(0.0, 0.0, 0.1);
                 PtVec3 u_basis = pt_cross(reflect_dir, off);
                 PtVec3 v_basis = pt_cross(reflect_dir, u_basis);
+                const uint32_t sample = pt_lane_sample(a, L.item);
                 uint64_t pixel = (uint64_t)L.y * a.width + L.x;
-                double u_coord = -glossy / 2.0 + pt_rng_f64(a.seed, pixel, L.sample, L.draw) * glossy;
-                double v_coord = -glossy / 2.0 + pt_rng_f64(a.seed, pixel, L.sample, L.draw + 1) * glossy;
+                double u_coord = -glossy / 2.0 + pt_rng_f64(a.seed, pixel, sample, L.draw) * glossy;
+                double v_coord = -glossy / 2.0 + pt_rng_f64(a.seed, pixel, sample, L.draw + 1) * glossy;
                 L.draw += 2;
                 reflect_dir = reflect_dir + (u_basis * u_coord + v_basis * v_coord);
             }
