@@ -6,7 +6,8 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 c = {}
-for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
+newest = lambda pattern: [max(glob.glob(pattern), key=os.path.getmtime)] if glob.glob(pattern) else []
+for f in [x for d in glob.glob(f"{src}/pmc_*") for x in newest(f"{d}/*/*_counter_collection.csv")]:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if re.search(r"pt_render_kernel<\d+, false,", r["Kernel_Name"]):
@@ -14,7 +15,7 @@ for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
     for k, v in agg.items():
         c[k] = sum(v) / len(v)
 ms = name = None
-for f in glob.glob(f"{src}/trace/*/*_kernel_stats.csv"):
+for f in newest(f"{src}/trace/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if re.search(r"pt_render_kernel<\d+, false,", r["Name"]):
             ms, name = float(r["AverageNs"]) / 1e6, r["Name"]

@@ -9,11 +9,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0], f"{dst}/{tag}_kernel_stats.csv")
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)  # gpurun merges every call's output into the same directory: take the last run's file
+shutil.copy(newest(f"{src}/trace/*/*_kernel_stats.csv"), f"{dst}/{tag}_kernel_stats.csv")
 timed = r"pt_render_kernel<\d+, false,"  # the timed kernel (STATS = false), not the counting launch
 out = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
-    for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
+    for f in [newest(f"{src}/{d}/*/*_counter_collection.csv")]:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if re.search(timed, r["Kernel_Name"]):
