@@ -68,32 +68,67 @@ __global__ void __launch_bounds__(256) pt_copy_kernel(const double2* __restrict_
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
-// Two-child tree -> four-child tree (PtBvh4Node, pt_scene_view.h): node i takes over the children of its inner children.
+// Two-child tree -> four-child tree (PtBvh4Node, pt_scene_view.h). Node i starts with its two children and, while it has
+// fewer than four, replaces the inner child with the largest surface area by that child's two children (the child a ray is
+// most likely to enter is the one worth opening; taking over both children's children regardless leaves a node with a leaf
+// child at three entries). Mesh trees only: on scene-level trees the grandchildren form measured better (transmission-refraction
+// 3.32 against 3.72 node visits per ray). PORTRAYER_COLLAPSE=plain | mesh | area.
 // One thread per two-child node; entries of the array that no tree uses (the device build reserves n - 1 nodes per mesh
 // and may need fewer) hold garbage, are never referenced, and are only kept from reading out of bounds.
-__global__ void __launch_bounds__(256) pt_collapse4_kernel(const PtBvhNode* __restrict__ bvh2, PtBvh4Node* __restrict__ bvh4, uint32_t n) {
+__global__ void __launch_bounds__(256) pt_collapse4_kernel(const PtBvhNode* __restrict__ bvh2, PtBvh4Node* __restrict__ bvh4, uint32_t n, int by_area_mode,
+                                                            uint32_t scene_first, uint32_t scene_end) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // by_area_mode 0: never, 1: mesh trees only (nodes outside [scene_first, scene_end)), 2: every tree
+    const bool by_area = by_area_mode == 2 || (by_area_mode == 1 && (i < scene_first || i >= scene_end));
     const PtBvhNode a = bvh2[i];
-    PtBvh4Node o;
+    float lo[4][3], hi[4][3];
+    uint32_t child[4];
     int k = 0;
-    auto put = [&](const float* lo, const float* hi, uint32_t child) {
-        for (int ax = 0; ax < 3; ax++) { o.lo[ax][k] = lo[ax]; o.hi[ax][k] = hi[ax]; }
-        o.child[k] = child;
+    auto put = [&](const float* l, const float* h, uint32_t c) {
+        for (int ax = 0; ax < 3; ax++) { lo[k][ax] = l[ax]; hi[k][ax] = h[ax]; }
+        child[k] = c;
         k++;
     };
-    auto expand = [&](const float* lo, const float* hi, uint32_t child) {
-        if (child == PT_REF_EMPTY) return;
-        if ((child & PT_REF_LEAF) || child >= n) { put(lo, hi, child); return; }
-        const PtBvhNode c = bvh2[child];
-        if (c.child0 != PT_REF_EMPTY) put(c.lo0, c.hi0, c.child0);
-        if (c.child1 != PT_REF_EMPTY) put(c.lo1, c.hi1, c.child1);
-    };
-    expand(a.lo0, a.hi0, a.child0);
-    expand(a.lo1, a.hi1, a.child1);
-    for (; k < 4; k++) {
-        for (int ax = 0; ax < 3; ax++) { o.lo[ax][k] = (float)PT_BOX_LIMIT; o.hi[ax][k] = -(float)PT_BOX_LIMIT; }
-        o.child[k] = PT_REF_EMPTY;
+    auto inner = [&](uint32_t c) { return c != PT_REF_EMPTY && !(c & PT_REF_LEAF) && c < n; };
+    if (by_area) {
+        if (a.child0 != PT_REF_EMPTY) put(a.lo0, a.hi0, a.child0);
+        if (a.child1 != PT_REF_EMPTY) put(a.lo1, a.hi1, a.child1);
+        while (k < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int j = 0; j < k; j++) {
+                if (!inner(child[j])) continue;
+                const float dx = hi[j][0] - lo[j][0], dy = hi[j][1] - lo[j][1], dz = hi[j][2] - lo[j][2];
+                const float area = dx * dy + dy * dz + dz * dx;
+                if (!(area <= best_area)) { best = j; best_area = area; }  // also takes a NaN / infinite area rather than nothing
+            }
+            if (best < 0) break;
+            const PtBvhNode c = bvh2[child[best]];
+            const int n_kids = (c.child0 != PT_REF_EMPTY) + (c.child1 != PT_REF_EMPTY);
+            if (n_kids == 0) { child[best] = child[k - 1]; for (int ax = 0; ax < 3; ax++) { lo[best][ax] = lo[k - 1][ax]; hi[best][ax] = hi[k - 1][ax]; } k--; continue; }
+            // the first child takes the opened entry's place, the second goes to the end
+            const bool first0 = c.child0 != PT_REF_EMPTY;
+            for (int ax = 0; ax < 3; ax++) { lo[best][ax] = first0 ? c.lo0[ax] : c.lo1[ax]; hi[best][ax] = first0 ? c.hi0[ax] : c.hi1[ax]; }
+            child[best] = first0 ? c.child0 : c.child1;
+            if (n_kids == 2) put(c.lo1, c.hi1, c.child1);
+        }
+    } else {
+        auto expand = [&](const float* l, const float* h, uint32_t c0) {
+            if (c0 == PT_REF_EMPTY) return;
+            if (!inner(c0)) { put(l, h, c0); return; }
+            const PtBvhNode c = bvh2[c0];
+            if (c.child0 != PT_REF_EMPTY) put(c.lo0, c.hi0, c.child0);
+            if (c.child1 != PT_REF_EMPTY) put(c.lo1, c.hi1, c.child1);
+        };
+        expand(a.lo0, a.hi0, a.child0);
+        expand(a.lo1, a.hi1, a.child1);
+    }
+    PtBvh4Node o;
+    for (int j = 0; j < 4; j++) {
+        const bool used = j < k;
+        for (int ax = 0; ax < 3; ax++) { o.lo[ax][j] = used ? lo[j][ax] : (float)PT_BOX_LIMIT; o.hi[ax][j] = used ? hi[j][ax] : -(float)PT_BOX_LIMIT; }
+        o.child[j] = used ? child[j] : PT_REF_EMPTY;
     }
     o.pad[0] = o.pad[1] = o.pad[2] = o.pad[3] = 0u;
     bvh4[i] = o;
@@ -281,6 +316,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     std::vector<uint32_t> items;
     std::vector<PtBuildBox> mesh_box(s->n_meshes);
     int max_blas_depth = 0;
+    int collapse_mode = 1;  // how two-child trees become four-child trees (pt_collapse4_kernel): 0 grandchildren, 1 mesh trees opened by area, 2 every tree by area
     int blas_leaf = 2;  // triangles per mesh-tree leaf (measured: 2 beats 1, 3 and 4 by 2-5 % on cows / big-soup)
     if (const char* e = getenv("PORTRAYER_BLAS_LEAF")) blas_leaf = std::min(std::max(1, atoi(e)), 8);
     // Where a mesh's triangle tree is built: on the host (binned SAH, pt_bvh.h: the better tree) or on the
@@ -493,7 +529,9 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     int tlas_leaf = 1;  // primitive tests (f64, ~200 instructions) cost far more than a node visit: measured best on big-scene
     if (const char* e = getenv("PORTRAYER_TLAS_LEAF")) tlas_leaf = std::max(1, atoi(e));
     const bool tlas_direct = tlas_leaf == 1 && n < (1u << 28);
+    const size_t tlas_first = bvh.size();
     PtBvhRef tlas = pt_bvh_build(node_box.data(), nullptr, n, tlas_leaf, bvh, items, tlas_direct);
+    const size_t tlas_end = bvh.size();
 
     // ---- k-d tree (reference structure, KD mode)
     std::vector<PtKdNode> kdn;
@@ -583,9 +621,10 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         if (verbose && !device_meshes.empty()) fprintf(stderr, "[pt_scene_upload] device tree build: %zu mesh(es), %.2f ms, %d clustering rounds, depth %d\n", device_meshes.size(), device_ms, rounds, max_blas_depth);
         lap("device mesh trees");
         // the walks read the four-child form of every tree (scene tree and mesh trees alike)
+        if (const char* e = getenv("PORTRAYER_COLLAPSE")) collapse_mode = strcmp(e, "plain") == 0 ? 0 : (strcmp(e, "area") == 0 ? 2 : 1);
         if ((rc = pt_reserve(c, c->bvh4, std::max<size_t>(n_nodes, 1) * sizeof(PtBvh4Node)))) return rc;
         if (n_nodes) {
-            hipLaunchKernelGGL(pt_collapse4_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, nullptr, (const PtBvhNode*)c->bvh.p, (PtBvh4Node*)c->bvh4.p, (uint32_t)n_nodes);
+            hipLaunchKernelGGL(pt_collapse4_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, nullptr, (const PtBvhNode*)c->bvh.p, (PtBvh4Node*)c->bvh4.p, (uint32_t)n_nodes, collapse_mode, (uint32_t)tlas_first, (uint32_t)tlas_end);
             PT_HIP(c, hipGetLastError());
             PT_HIP(c, hipDeviceSynchronize());
         }
@@ -693,8 +732,9 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
         v.chain_off = (const uint32_t*)c->chain_off.p; v.chain = (const uint32_t*)c->chain.p; v.dfs_rank = (const uint32_t*)c->dfs_rank.p;
     }
-    // a level of the four-child walk pushes up to three pending children and covers two levels of the two-child tree
-    auto wide = [](int depth2) { return 3 * ((depth2 + 1) / 2); };
+    // a level of the four-child walk pushes up to three pending children; it covers two levels of the two-child tree in the plain
+    // collapse and at least one when nodes are opened by area
+    auto wide = [&](int depth2) { return collapse_mode ? 3 * depth2 : 3 * ((depth2 + 1) / 2); };
     int below = std::max(wide(max_blas_depth), 3 * (max_kdm_depth + 1));  // deepest walk under a scene leaf: a mesh tree or a KDMesh tree
     int cap = traverse == PT_TRAVERSE_KD ? 3 * (kd_depth + 1) + below + 2 : wide(tlas.depth) + below + 4;
     v.stack_cap = std::max(cap, 8);
