@@ -98,7 +98,8 @@ def roofline_block(workload, traversal, world, at_config_size, algorithmic, kern
             "basis": ("HBM-side bytes per launch from %s" % prof.get("source", "profiles/traffic.json")) if traffic else "no PMC profile of this exact workload is committed: achieved / frac are null",
             "kernel": "pt_render_kernel", "kernel_ms": kernel_s * 1e3,
             "algorithmic": {"bytes_per_launch": algorithmic, "GBps": algorithmic / kernel_s / 1e9,
-                            "note": "SURVEY 8(d) per-ray operand bytes x the kernel's own counters; cache-served, NOT HBM traffic"},
+                            "over_measured_copy_bandwidth": algorithmic / kernel_s / 1e9 / copy_gbps,
+                            "note": "SURVEY 8(d) per-ray operand bytes x the kernel's own counters; cache-served, NOT HBM traffic (a ratio above 1 is what that means)"},
             # MI355X vector f64 = 78.6 TFLOP/s counting an fma as 2; parity forbids contraction, so 39.3 T mul-or-add/s
             "valu": {"achieved": flops / kernel_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / kernel_s / 1e12 / VALU_PEAK_TFLOPS,
                      "lanes_active_of_64": prof.get("lanes_active") if prof else None, "valu_busy": prof.get("valu_busy") if prof else None},

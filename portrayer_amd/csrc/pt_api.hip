@@ -68,6 +68,12 @@ __global__ void __launch_bounds__(256) pt_copy_kernel(const double2* __restrict_
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// the plainest form: one 16-byte element per thread, as many blocks as it takes
+__global__ void __launch_bounds__(256) pt_copy1_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // Two-child tree -> four-child tree (PtBvh4Node, pt_scene_view.h). Node i starts with its two children and, while it has
 // fewer than four, replaces the inner child with the largest surface area by that child's two children (the child a ray is
 // most likely to enter is the one worth opening; taking over both children's children regardless leaves a node with a leaf
@@ -1073,15 +1079,24 @@ extern "C" int pt_measure_copy_bandwidth(pt_context* c, uint64_t bytes, int iter
     PT_HIP(c, hipMemset(src, 1, bytes));
     size_t n = bytes / 16;
     double best = 0.0;
-    const int per_cu[4] = {8, 16, 32, 64};  // resident copy blocks per CU: the best of a few grid sizes is the box's roofline
-    for (int i = 0; i < 4 * iters + 1; i++) {
+    // The box's copy roofline = the best of a few ways to copy: a grid-stride kernel with four loads in flight at four grid
+    // sizes, one element per thread, and the runtime's own device-to-device copy.
+    const int per_cu[4] = {8, 16, 32, 64};
+    for (int i = 0; i < 6 * iters + 1; i++) {
+        const int form = i % 6;
         PT_HIP(c, hipEventRecord(c->ev0, nullptr));
-        hipLaunchKernelGGL(pt_copy_kernel, dim3(c->n_cu * per_cu[i % 4]), dim3(256), 0, nullptr, (const double2*)src, (double2*)dst, n);
+        if (form < 4) hipLaunchKernelGGL(pt_copy_kernel, dim3(c->n_cu * per_cu[form]), dim3(256), 0, nullptr, (const double2*)src, (double2*)dst, n);
+        else if (form == 4) hipLaunchKernelGGL(pt_copy1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const double2*)src, (double2*)dst, n);
+        else PT_HIP(c, hipMemcpyAsync(dst, src, n * 16, hipMemcpyDeviceToDevice, nullptr));
         PT_HIP(c, hipEventRecord(c->ev1, nullptr));
         PT_HIP(c, hipEventSynchronize(c->ev1));
         float ms = 0.f;
         PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        if (i > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)(n * 16) / (ms * 1e-3) / 1e9);
+        if (i > 0 && ms > 0.f) {
+            const double rate = 2.0 * (double)(n * 16) / (ms * 1e-3) / 1e9;
+            if (getenv("PORTRAYER_VERBOSE")) fprintf(stderr, "[pt_measure_copy_bandwidth] form %d: %.0f GB/s\n", form, rate);
+            best = std::max(best, rate);
+        }
     }
     hipFree(src); hipFree(dst);
     *gbps = best;
