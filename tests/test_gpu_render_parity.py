@@ -425,6 +425,32 @@ def test_traversal_stack_beyond_lds_gives_the_same_image(host, H, monkeypatch, n
         assert out[None][2][k] == out["1"][2][k], k
 
 
+@pytest.mark.parametrize("env", [{"PORTRAYER_COLLAPSE": "plain"}, {"PORTRAYER_COLLAPSE": "area"}, {"PORTRAYER_FINE_QUEUES": "0"}, {"PORTRAYER_FINE_QUEUES": "1"},
+                                 {"PORTRAYER_FINE_QUEUES": "64"}, {"PORTRAYER_FINE_QUEUES": "0", "PORTRAYER_BATCH_MAX": "1"},
+                                 {"PORTRAYER_FINE_QUEUES": "0", "PORTRAYER_ITEM_STRIDE": "golden"}, {"PORTRAYER_LANE_CHUNKS": "1"}])
+@pytest.mark.parametrize("name,mode", [("entering-the-mirror-dimension", "flat"), ("macho-cows", "hier")])
+def test_scheduling_and_tree_shape_do_not_change_the_image(host, H, monkeypatch, name, mode, env):
+    """How work items are handed out (guided batches, interleaved single-item queues, a scattered order), how many chunks of a
+    pixel a wavefront runs side by side and which four-child form the trees take are performance choices with defaults picked
+    per scene; every other setting must give the same image, linear values and ray counts."""
+    scene = host.Scene.example(name)
+    tr = H.TRAVERSE_FLAT if mode == "flat" else H.TRAVERSE_HIER
+    w, h = 203, 117
+    out = []
+    for setting in ({}, env):
+        for k, v in setting.items():
+            monkeypatch.setenv(k, v)
+        r = host.Renderer(scene, tr)
+        rgb, linear, st = r.render(scene.camera, w, h, default_background(w, h), samples=16, seed=5, sample_mode=H.SAMPLE_RNG, stats=True)
+        plain, _, _ = r.render(scene.camera, w, h, default_background(w, h), samples=16, seed=5, sample_mode=H.SAMPLE_RNG)
+        assert np.array_equal(plain, rgb) and st["stack_overflow"] == 0
+        out.append((rgb, linear, st))
+        r.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert out[0][2][k] == out[1][2][k], k
+
+
 def test_device_build_of_a_large_mesh_matches_oracle(oracle, host, H, monkeypatch):
     from example_scenes import SYNTHETIC
     scene, cam, _ = SYNTHETIC["big-soup"](3)  # 27 cows baked into one 156,708-triangle mesh: above the automatic threshold
