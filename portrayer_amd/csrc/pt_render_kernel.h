@@ -146,6 +146,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
                 if (tracing) { cnt.diag[1]++; if (L.ray_any) cnt.diag[7]++; }
             }
 #endif
+#ifndef PT_NO_PACKET
+            // scenes of analytic primitives whose hits spawn no rays: one walk per wavefront (pt_trace_packet); every lane calls it
+            if ((MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) && PARK == 0) {
+                if (__any(tracing))
+                    pt_trace_packet<STATS, MODE == PT_MODE_HIER_NOMESH>(a.scene, L.ray, tracing, L.ray_any, hit, pt_lds + (threadIdx.x & ~63u), a.stack_lds_cap,
+                                                                       a.overflow_flag, &cnt);
+            } else
+#endif
             if (tracing) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
 #ifdef PT_CYCLES
             if (STATS && lane == 0) { const unsigned long long cyc_c = __builtin_readcyclecounter(); cnt.diag[2] += cyc_b - cyc_a; cnt.diag[0] += cyc_c - cyc_b; cnt.diag[1]++; }

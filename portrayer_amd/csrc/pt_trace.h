@@ -800,6 +800,224 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
     return best.node != PT_NO_HIT;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE walk per wavefront (scenes of analytic primitives whose hits spawn no rays: PT_MODE_FLAT_NOMESH / HIER_NOMESH, PARK = 0).
+//
+// The 64 rays of a wavefront pass through one pixel (or a few) and visit nearly the same nodes - the per-lane walk has 61.8 of
+// 64 lanes busy per step on big-scene - so the node index and the stack can be WAVE-UNIFORM instead of per lane:
+//  * a node is fetched once per wavefront, through the scalar cache into SGPRs (s_load_dwordx16), and its boxes are scalar
+//    operands of the 64 slab tests; the stack is one list in the wavefront's LDS columns; no lane keeps a node index, a stack
+//    pointer or a stack column;
+//  * a child is entered when ANY lane's ray reaches its box - each lane tests with its own nearest hit so far - and the child
+//    most of those lanes call nearer is entered first. Every live lane tests what the wavefront visits (a test below a box its
+//    ray misses finds nothing and costs no time: the instruction is issued for the others anyway). The counting build also
+//    carries, per stack entry, the mask of the lanes whose rays reach the subtree, and counts a lane's steps and tests only
+//    there - what a per-lane walk in the same order would count; carrying the masks in the timed build cost 6 %;
+//  * in a leaf the flattened node's record (type, inverse transform) is again one scalar fetch for all lanes.
+// The result of a ray does not depend on the order of the walk or on which other candidates are tested (FLAT: nearest hit,
+// lowest index on exact ties; HIER: nearest hit, first in depth-first order), so this is a change of schedule, not of results.
+// Measured on big-scene: 16.6 -> 19.0 Gray/s with the first version (profiles/r02/notes.md). -DPT_NO_PACKET keeps the per-lane walk.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t pt_u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t pt_u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
+PT_HD pt_u32x16 pt_sload16(const void* p) {
+    pt_u32x16 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+#else
+    v = *static_cast<const pt_u32x16*>(p);
+#endif
+    return v;
+}
+PT_HD pt_u32x8 pt_sload8(const void* p) {
+    pt_u32x8 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+#else
+    v = *static_cast<const pt_u32x8*>(p);
+#endif
+    return v;
+}
+PT_HD pt_u32x4 pt_sload4(const void* p) {
+    pt_u32x4 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+#else
+    v = *static_cast<const pt_u32x4*>(p);
+#endif
+    return v;
+}
+PT_HD double pt_f64_of(uint32_t lo, uint32_t hi) {
+    union { double d; uint32_t u[2]; } c;
+    c.u[0] = lo; c.u[1] = hi;
+    return c.d;
+}
+PT_HD float pt_f32_of(uint32_t u) {
+    union { float f; uint32_t u; } c;
+    c.u = u;
+    return c.f;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_UNIFORM_U32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define PT_BALLOT(x) __ballot(x)
+#define PT_LANE_ID() (threadIdx.x & 63u)
+#else
+#define PT_UNIFORM_U32(x) ((uint32_t)(x))
+#define PT_BALLOT(x) ((x) ? 1ull : 0ull)
+#define PT_LANE_ID() 0u
+#endif
+
+// 12 doubles (rows 0..2 of a 3x4 matrix) at a wave-uniform address, in one round trip through the scalar cache
+PT_HD void pt_sload_mat12(const double* p, double m[12]) {
+    pt_u32x16 a;
+    pt_u32x8 b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+#else
+    a = *reinterpret_cast<const pt_u32x16*>(p);
+    b = *reinterpret_cast<const pt_u32x8*>(reinterpret_cast<const char*>(p) + 64);
+#endif
+#pragma unroll
+    for (int k = 0; k < 8; k++) m[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) m[8 + k] = pt_f64_of(b[2 * k], b[2 * k + 1]);
+}
+// pt_node_local_ray<true> for a wave-uniform node: the path and every SceneNode's inverse come through the scalar cache
+PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray) {
+    const uint32_t k0 = PT_UNIFORM_U32(sc.chain_off[node]), k1 = PT_UNIFORM_U32(sc.chain_off[node + 1]);
+    PtRay r = ray;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t g = PT_UNIFORM_U32(sc.chain[k]);
+        double m[12];
+        pt_sload_mat12(sc.g_inv + 12 * (size_t)g, m);
+        r = pt_ray_to_local(m, r);
+    }
+    return r;
+}
+
+// One flattened node against every participating lane's ray; `node` is wave-uniform.
+template <bool STATS, bool HIER>
+PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray, PtHit& best, PtCounters* cnt) {
+    // the node's record in one round trip through the scalar cache: {type, data, flags, material} and rows 0..2 of its inverse
+    pt_u32x4 info;
+    pt_u32x16 a;  // doubles 0..7 of the 3x4 inverse
+    pt_u32x8 b;   // doubles 8..11
+    const void* info_ptr = sc.info + 4 * (size_t)node;
+    const void* rec = sc.inv + 12 * (size_t)node;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (HIER) {
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(info) : "s"(info_ptr) : "memory");
+    } else {
+        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(info), "=&s"(a), "=&s"(b) : "s"(info_ptr), "s"(rec) : "memory");
+    }
+#else
+    info = *static_cast<const pt_u32x4*>(info_ptr);
+    a = *static_cast<const pt_u32x16*>(rec);
+    b = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(rec) + 64);
+#endif
+    const uint32_t type = info[0], data = info[1];
+    PtRay local;
+    if (HIER) {
+        local = pt_node_local_ray_uniform(sc, node, ray);
+    } else {
+        double m[12];
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) m[8 + k] = pt_f64_of(b[2 * k], b[2 * k + 1]);
+        local = pt_ray_to_local(m, ray);
+    }
+    if (STATS) cnt->n_analytic++;
+    double t;
+    uint32_t part = 0;
+    bool hit;
+    if (type == PT_TRIANGLE) {  // stand-alone triangle, stored after the mesh triangles
+        double beta, gamma;
+        if (STATS) cnt->n_tri++;
+        hit = pt_triangle_hit(sc.tri_v + 9 * (size_t)data, local, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, data), &t, &beta, &gamma);
+        part = data;
+    } else {
+        hit = pt_unit_prim_hit(type, local, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, 0), &t, &part);
+    }
+    if (!hit) return false;
+    best.t = t; best.node = node; best.sub = part;
+    return true;
+}
+
+// wstack: the wavefront's LDS columns (entry k at wstack[(k >> 6) * PT_BLOCK + (k & 63)]), wcap * 64 words in all.
+template <bool STATS, bool HIER>
+PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wcap,
+                           unsigned int* overflow, PtCounters* cnt) {
+    if (has_ray) { best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0; }
+    if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return;
+    const unsigned long long self = 1ull << PT_LANE_ID();
+    bool alive = has_ray;               // the lane still wants candidates (a shadow ray stops at its first hit)
+    unsigned long long in = ~0ull;      // wave-uniform: lanes whose rays reach the current node's box
+    const PtRay32 q = pt_ray32(ray);
+    uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
+    int sp = 0;                          // words on the stack
+    constexpr int W = STATS ? 3 : 1;     // per entry: the node, and in the counting build the mask of the lanes that reach it
+    auto slot = [&](int k) -> uint32_t& { return wstack[(k >> 6) * PT_BLOCK + (k & 63)]; };
+    const int words = wcap * 64 < W * sc.stack_cap ? wcap * 64 : W * sc.stack_cap;  // scene.stack_cap entries, if the LDS columns hold them
+    for (;;) {
+        while (!(cur & PT_REF_LEAF)) {
+            const pt_u32x16 v = pt_sload16(sc.bvh + cur);
+            const bool mine = alive && (!STATS || (in & self));
+            if (STATS && mine) cnt->n_inner++;
+            float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;  // rounded up, like the per-lane walk
+            const float lo0[3] = {pt_f32_of(v[0]), pt_f32_of(v[1]), pt_f32_of(v[2])}, hi0[3] = {pt_f32_of(v[3]), pt_f32_of(v[4]), pt_f32_of(v[5])};
+            const float lo1[3] = {pt_f32_of(v[6]), pt_f32_of(v[7]), pt_f32_of(v[8])}, hi1[3] = {pt_f32_of(v[9]), pt_f32_of(v[10]), pt_f32_of(v[11])};
+            float t0, t1;
+            const bool h0 = pt_slab32(lo0, hi0, q, tm, &t0) && mine;
+            const bool h1 = pt_slab32(lo1, hi1, q, tm, &t1) && mine;
+            const unsigned long long m0 = PT_BALLOT(h0), m1 = PT_BALLOT(h1);
+            const uint32_t c0 = v[12], c1 = v[13];
+            if (m0 && m1) {
+                const unsigned long long second_first = PT_BALLOT(h1 && (!h0 || t1 < t0));  // lanes that would enter child 1 first
+                const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
+                if (sp + W > words) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if (overflow) atomicOr(overflow, 1u);
+#endif
+                    if (STATS) cnt->stack_overflow++;
+                    if (has_ray) best.node = PT_NO_HIT;
+                    return;
+                }
+                const unsigned long long far_mask = swap ? m0 : m1;
+                slot(sp) = swap ? c0 : c1;
+                if (STATS) { slot(sp + 1) = (uint32_t)far_mask; slot(sp + 2) = (uint32_t)(far_mask >> 32); }
+                sp += W;
+                cur = swap ? c1 : c0; in = swap ? m1 : m0;
+            } else if (m0) {
+                cur = c0; in = m0;
+            } else if (m1) {
+                cur = c1; in = m1;
+            } else {
+                if (sp == 0) return;
+                sp -= W;
+                cur = PT_UNIFORM_U32(slot(sp));
+                if (STATS) in = (unsigned long long)PT_UNIFORM_U32(slot(sp + 1)) | ((unsigned long long)PT_UNIFORM_U32(slot(sp + 2)) << 32);
+            }
+        }
+        const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+        for (uint32_t i = 0; i < count; i++) {
+            const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
+            if (alive && (!STATS || (in & self))) {
+                if (STATS) cnt->n_leaf++;
+                if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, best, cnt) && any) alive = false;
+            }
+        }
+        if (!PT_BALLOT(alive)) return;
+        if (sp == 0) return;
+        sp -= W;
+        cur = PT_UNIFORM_U32(slot(sp));
+        if (STATS) in = (unsigned long long)PT_UNIFORM_U32(slot(sp + 1)) | ((unsigned long long)PT_UNIFORM_U32(slot(sp + 2)) << 32);
+    }
+}
+
 // Traversal of one ray in the semantics of `MODE` (PT_MODE_*).
 template <int MODE, bool STATS, class Stack>
 PT_HD void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const Stack& stk, PtCounters* cnt) {
