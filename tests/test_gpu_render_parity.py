@@ -193,6 +193,82 @@ def random_scene(seed, with_mesh=True):
     return scene, cam
 
 
+def analytic_scene(seed):
+    """Analytic primitives and stand-alone triangles only, nothing reflective: the scenes the render kernel walks ONCE PER
+    WAVEFRONT (pt_trace_packet). 20 - 150 primitives in nested, transformed, partly shared groups (hierarchical chains of
+    depth 2 - 4), touching and overlapping shapes, thin and tiny ones, a camera inside the cloud now and then, area lights."""
+    rng = np.random.default_rng(7000 + seed)
+    mats = [Material(diffuse=tuple(rng.uniform(0, 1, 3)), specular=tuple(rng.uniform(0, 0.9, 3)) if i % 3 else (0, 0, 0),
+                     shininess=float(rng.choice([0.0, 1.0, 25.0, 300.0]))) for i in range(5)]
+    prims = [Sphere, Cube, Plane, Cylinder, Cone]
+
+    def leaf(spread):
+        k = int(rng.integers(0, len(prims) + 1))
+        if k < len(prims):
+            p = prims[k]()
+        else:
+            v = rng.uniform(-1, 1, (3, 3))
+            p = Triangle(v[0], v[1], v[2], normals=rng.uniform(-1, 1, (3, 3)) if rng.random() < 0.5 else None)
+        n = Node.geo(p, mats[int(rng.integers(0, len(mats)))])
+        s = np.exp(rng.uniform(-2.5, 0.7, 3))
+        if rng.random() < 0.15:
+            s[int(rng.integers(0, 3))] *= 1e-3
+        n.scaled(tuple(s))
+        if rng.random() < 0.7:
+            n.rotated_xzy(tuple(rng.uniform(-3.1, 3.1, 3)))
+        n.translated(tuple(rng.uniform(-spread, spread, 3)))
+        return n
+
+    def group(depth, spread):
+        kids = [leaf(spread) for _ in range(int(rng.integers(2, 7)))]
+        if depth > 0:
+            kids += [group(depth - 1, spread * 0.6) for _ in range(int(rng.integers(1, 3)))]
+        g = Node.group(kids)
+        if rng.random() < 0.6:  # some groups keep the identity
+            g.scaled(tuple(rng.uniform(0.5, 1.5, 3)))
+            g.rotated_xzy(tuple(rng.uniform(-1.0, 1.0, 3)))
+            g.translated(tuple(rng.uniform(-spread, spread, 3)))
+        return g
+
+    shared = group(1, 1.0)
+    kids = [group(int(rng.integers(0, 3)), 3.0) for _ in range(int(rng.integers(3, 8)))]
+    kids += [Node.group([shared]).translated(tuple(rng.uniform(-3, 3, 3))) for _ in range(2)]
+    kids.append(Node.geo(Plane(), mats[0]).scaled(40.0).translated((0.0, -3.0, 0.0)))
+    kids.append(Node.geo(Cube(), mats[1]).translated((0.0, 0.0, 0.0)))
+    kids.append(Node.geo(Cube(), mats[2]).translated((1.0, 0.0, 0.0)))  # shares a face with the one before: exact ties
+    lights = [Light(position=tuple(rng.uniform(-8, 8, 3) + np.array([0, 10, 0])), color=tuple(rng.uniform(0.3, 0.9, 3))),
+              Light(position=(4.0, 6.0, 9.0), color=(0.6, 0.6, 0.6), falloff=(1.0, 0.01, 0.002),
+                    area_a=(0.5, 0.0, 0.0) if seed % 2 else (0.0, 0.0, 0.0), area_b=(0.0, 0.0, 0.5)),
+              Light(position=(-6.0, 2.0, -4.0), color=(0.3, 0.2, 0.2))]
+    root = Node.group(kids)
+    if seed % 3 == 0:
+        root.rotated_y(float(rng.uniform(-0.5, 0.5)))
+    eye = (0.5, 2.0, 11.0) if seed % 4 else (0.2, 0.3, 0.4)  # now and then from inside the cloud
+    return Scene(root=root, lights=lights, ambient=tuple(rng.uniform(0.1, 0.4, 3))), Camera(eye=eye, center=(0.0, 0.0, 0.0), fovy_degrees=40.0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("mode,samples", [("flat", 2), ("hier", 2), ("flat", 64), ("hier", 19)])
+def test_mesh_free_scene_without_reflection_matches_oracle(oracle, host, H, seed, mode, samples):
+    """The wave-uniform walk (one per wavefront) against the oracle: 32 pixels x 2 samples, one pixel x 64 samples and a
+    ragged sample count per wavefront; flat_scene and hierarchical semantics."""
+    scene, cam = analytic_scene(seed)
+    hs = host_glue.host_scene(scene)
+    w, h = (104, 72) if samples < 10 else (40, 28)
+    tr, om = (H.TRAVERSE_FLAT, oracle.MODE_FLAT) if mode == "flat" else (H.TRAVERSE_HIER, oracle.MODE_HIER)
+    r = host.Renderer(hs, tr)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=samples, seed=seed, sample_mode=H.SAMPLE_RNG, stats=True)
+    plain, _, _ = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=samples, seed=seed, sample_mode=H.SAMPLE_RNG)
+    r.close()
+    ref = oracle.render(scene, cam, w, h, samples=samples, seed=seed, jitter=oracle.JITTER_RNG, mode=om)
+    assert st["reflect"] == 0 and st["stack_overflow"] == 0
+    for k in ("primary", "shadow", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert np.array_equal(rgb, ref.rgb), f"{(rgb != ref.rgb).any(axis=2).sum()} pixels differ"
+    assert np.array_equal(plain, rgb)
+    assert_ulp(linear, ref.linear, 8)
+
+
 @pytest.mark.parametrize("seed", range(8))
 @pytest.mark.parametrize("mode", ["flat", "kd"])
 def test_random_scene_matches_oracle(oracle, host, H, seed, mode):
