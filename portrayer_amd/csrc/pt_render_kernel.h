@@ -147,11 +147,26 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
             }
 #endif
 #ifndef PT_NO_PACKET
-            // scenes of analytic primitives whose hits spawn no rays: one walk per wavefront (pt_trace_packet); every lane calls it
-            if ((MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) && PARK == 0) {
+            // One walk per wavefront (pt_trace_packet / pt_trace_packet_mesh; every lane calls it) in the flat_scene and hierarchical
+            // semantics. The wavefront's stack takes the LAST rows of its LDS columns where lanes also need a stack of their own
+            // (KDMesh trees), all of them otherwise. The k-d tree semantics keep the per-lane walk (per-ray ranges and order).
+            if (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) {
                 if (__any(tracing))
                     pt_trace_packet<STATS, MODE == PT_MODE_HIER_NOMESH>(a.scene, L.ray, tracing, L.ray_any, hit, pt_lds + (threadIdx.x & ~63u), a.stack_lds_cap,
                                                                        a.overflow_flag, &cnt);
+            } else if (MODE == PT_MODE_FLAT) {
+                if (__any(tracing))
+                    pt_trace_packet_mesh<STATS, false, false>(a.scene, L.ray, tracing, L.ray_any, hit, pt_lds + (threadIdx.x & ~63u), a.stack_lds_cap, stk,
+                                                              a.overflow_flag, &cnt);
+            } else if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
+                if (__any(tracing)) {
+                    const int rows = a.stack_lds_cap >= 16 ? 4 : (a.stack_lds_cap >= 4 ? 2 : 1);  // of the wavefront's stack; the lanes' own stacks get the rest
+                    PtStackSpill lane_stk = stk;
+                    lane_stk.cap = a.stack_lds_cap - rows;
+                    pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, L.ray, tracing, L.ray_any, hit,
+                                                                            pt_lds + (size_t)lane_stk.cap * PT_BLOCK + (threadIdx.x & ~63u), rows, lane_stk,
+                                                                            a.overflow_flag, &cnt);
+                }
             } else
 #endif
             if (tracing) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);

@@ -1018,6 +1018,157 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     }
 }
 
+// The same for scenes WITH mesh instances (PT_MODE_FLAT, hits spawn no rays): the scene tree and every mesh's triangle tree are
+// walked once per wavefront. Entering a mesh instance is wave-uniform too: every lane brings its ray into the instance's space
+// with the one inverse transform (scalar operands), the lanes whose rays pass the mesh's exact box test (mesh.rs:146-155) take
+// part in its tree, a marker on the stack says where the scene tree continues. Triangle records (nine doubles) arrive through
+// the scalar cache like nodes. Two-child nodes throughout (the array the four-child form is made from).
+// KDMESH: KDMesh instances keep the reference's own triangle k-d tree (quirk Q3), which every lane walks by itself with its own
+// range bookkeeping (pt_kdmesh_hit) on `lane_stk`, a per-lane stack beside the wavefront's. HIER: the hierarchical semantics
+// (every SceneNode's own inverse on the way down, ties by depth-first rank).
+template <bool STATS, bool KDMESH, bool HIER, class LaneStack>
+PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wcap,
+                                const LaneStack& lane_stk, unsigned int* overflow, PtCounters* cnt) {
+    if (has_ray) { best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0; }
+    if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return;
+    bool alive = has_ray;     // the lane still wants candidates
+    bool part = has_ray;      // ... and takes part in the tree being walked (inside a mesh: its ray passed the mesh's box test)
+    PtRay local = ray;        // the ray in the space of the tree being walked
+    PtRay32 q = pt_ray32(ray);
+    uint32_t inst = PT_NO_HIT;  // wave-uniform: flat node of the mesh instance being walked
+    uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
+    int sp = 0;
+    auto slot = [&](int k) -> uint32_t& { return wstack[(k >> 6) * PT_BLOCK + (k & 63)]; };
+    const int words = wcap * 64 < sc.stack_cap ? wcap * 64 : sc.stack_cap;
+    auto overflowed = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (overflow) atomicOr(overflow, 1u);
+#endif
+        if (STATS) cnt->stack_overflow++;
+        if (has_ray) best.node = PT_NO_HIT;
+    };
+    for (;;) {
+        bool popped = false;
+        while (!(cur & PT_REF_LEAF)) {
+            const pt_u32x16 v = pt_sload16(sc.bvh + cur);
+            const bool mine = alive && part;
+            if (STATS && mine) cnt->n_inner++;
+            float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;
+            const float lo0[3] = {pt_f32_of(v[0]), pt_f32_of(v[1]), pt_f32_of(v[2])}, hi0[3] = {pt_f32_of(v[3]), pt_f32_of(v[4]), pt_f32_of(v[5])};
+            const float lo1[3] = {pt_f32_of(v[6]), pt_f32_of(v[7]), pt_f32_of(v[8])}, hi1[3] = {pt_f32_of(v[9]), pt_f32_of(v[10]), pt_f32_of(v[11])};
+            float t0, t1;
+            const bool h0 = pt_slab32(lo0, hi0, q, tm, &t0) && mine;
+            const bool h1 = pt_slab32(lo1, hi1, q, tm, &t1) && mine;
+            const unsigned long long m0 = PT_BALLOT(h0), m1 = PT_BALLOT(h1);
+            const uint32_t c0 = v[12], c1 = v[13];
+            if (m0 && m1) {
+                const unsigned long long second_first = PT_BALLOT(h1 && (!h0 || t1 < t0));
+                const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
+                if (sp + 1 > words) { overflowed(); return; }
+                slot(sp) = swap ? c0 : c1; sp++;
+                cur = swap ? c1 : c0;
+            } else if (m0) {
+                cur = c0;
+            } else if (m1) {
+                cur = c1;
+            } else {
+                popped = true;
+                break;
+            }
+        }
+        if (!popped) {
+            const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+            if (STATS && alive && part) cnt->n_leaf++;
+            if (inst != PT_NO_HIT) {  // triangles of the mesh being walked
+                for (uint32_t i = 0; i < count; i++) {
+                    const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[first + i]);
+                    const double* rec = sc.tri_v + 9 * (size_t)tri;
+                    pt_u32x16 a;
+                    uint32_t b0, b1;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    {
+                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                        u32x2 b;
+                        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(rec) : "memory");
+                        b0 = b[0]; b1 = b[1];
+                    }
+#else
+                    a = *reinterpret_cast<const pt_u32x16*>(rec);
+                    b0 = reinterpret_cast<const uint32_t*>(rec)[16]; b1 = reinterpret_cast<const uint32_t*>(rec)[17];
+#endif
+                    double tv[9];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) tv[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
+                    tv[8] = pt_f64_of(b0, b1);
+                    if (alive && part) {
+                        double tt, beta, gamma;
+                        if (STATS) cnt->n_tri++;
+                        if (pt_triangle_hit(tv, local, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, inst, tri), &tt, &beta, &gamma)) {
+                            best.t = tt; best.node = inst; best.sub = tri;
+                            if (any) alive = false;
+                        }
+                    }
+                }
+            } else {
+                bool entered = false;
+                for (uint32_t i = 0; i < count && !entered; i++) {
+                    const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
+                    const uint32_t type = PT_UNIFORM_U32(sc.info[4 * (size_t)node]);
+                    if (type == PT_MESH || type == PT_KDMESH) {
+                        const uint32_t data = PT_UNIFORM_U32(sc.info[4 * (size_t)node + 1]);
+                        const PtMeshInfo* mi = sc.meshes + data;
+                        PtRay lr;
+                        if (HIER) {
+                            lr = pt_node_local_ray_uniform(sc, node, ray);
+                        } else {
+                            double m[12];
+                            pt_sload_mat12(sc.inv + 12 * (size_t)node, m);
+                            lr = pt_ray_to_local(m, ray);
+                        }
+                        if (STATS && alive) cnt->n_analytic++;
+                        if (KDMESH && type == PT_KDMESH && (int32_t)PT_UNIFORM_U32((uint32_t)mi->kd_root) >= 0) {  // the reference's own triangle tree (quirk Q3)
+                            if (alive) {
+                                double t; uint32_t tri = 0;
+                                if (pt_kdmesh_hit<STATS>(sc, *mi, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, 0), lane_stk, 0, &t, &tri, cnt)) {
+                                    best.t = t; best.node = node; best.sub = tri;
+                                    if (any) alive = false;
+                                }
+                            }
+                            continue;
+                        }
+                        // mesh.rs:146-155: box test, then the triangles (also a KDMesh without a tree of its own: PORTRAYER_KDMESH_AS_MESH)
+                        const uint32_t root = PT_UNIFORM_U32(mi->blas_root);
+                        if (STATS && alive) cnt->n_bbox++;
+                        if (root == PT_REF_EMPTY) continue;
+                        double bi[12];
+                        pt_sload_mat12(mi->bbox_inv, bi);
+                        const bool inside = alive && pt_bbox_test_hit(bi, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, 0));
+                        if (!PT_BALLOT(inside)) continue;
+                        if (sp + 2 > words) { overflowed(); return; }
+                        if (i + 1 < count) { slot(sp) = PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2); sp++; }  // the rest of this leaf
+                        slot(sp) = PT_REF_MARKER; sp++;
+                        local = lr; q = pt_ray32(lr); part = inside; inst = node;
+                        cur = root;
+                        entered = true;
+                    } else if (alive) {
+                        if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, best, cnt) && any) alive = false;
+                    }
+                }
+                if (entered) continue;
+            }
+            if (!PT_BALLOT(alive)) return;
+        }
+        // the next pending subtree; a marker ends the walk of a mesh instance
+        for (;;) {
+            if (sp == 0) return;
+            sp--;
+            cur = PT_UNIFORM_U32(slot(sp));
+            if (cur != PT_REF_MARKER) break;
+            inst = PT_NO_HIT; local = ray; q = pt_ray32(ray); part = has_ray;
+        }
+    }
+}
+
 // Traversal of one ray in the semantics of `MODE` (PT_MODE_*).
 template <int MODE, bool STATS, class Stack>
 PT_HD void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const Stack& stk, PtCounters* cnt) {
