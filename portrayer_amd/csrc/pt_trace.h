@@ -1049,54 +1049,6 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     };
     for (;;) {
         bool popped = false;
-            va = *reinterpret_cast<const pt_u32x16*>(rec); vb = *reinterpret_cast<const pt_u32x16*>(rec + 64);
-#endif
-            const bool mine = alive && part;
-            if (STATS && mine) cnt->n_inner++;
-            float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;
-            float t[4];
-            uint32_t c[4] = {vb[8], vb[9], vb[10], vb[11]};
-            unsigned long long m[4];
-#pragma unroll
-            for (int ch = 0; ch < 4; ch++) {
-                const float lox = pt_f32_of(va[ch]), loy = pt_f32_of(va[4 + ch]), loz = pt_f32_of(va[8 + ch]);
-                const float hix = pt_f32_of(va[12 + ch]), hiy = pt_f32_of(vb[ch]), hiz = pt_f32_of(vb[4 + ch]);
-                float x0 = __builtin_fmaf(lox, q.ix, q.n0x), x1 = __builtin_fmaf(hix, q.ix, q.n1x);
-                float y0 = __builtin_fmaf(loy, q.iy, q.n0y), y1 = __builtin_fmaf(hiy, q.iy, q.n1y);
-                float z0 = __builtin_fmaf(loz, q.iz, q.n0z), z1 = __builtin_fmaf(hiz, q.iz, q.n1z);
-                float a = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                const float w = 9.6e-7f;
-                a = fmaxf(__builtin_fmaf(fabsf(a), -w, a), 0.0f);
-                f = fminf(__builtin_fmaf(fabsf(f), w, f), tm);
-                const bool h = !(a > f) && mine && c[ch] != PT_REF_EMPTY;
-                t[ch] = h ? a : INFINITY;
-                m[ch] = PT_BALLOT(h);
-            }
-            const unsigned long long any_mask = m[0] | m[1] | m[2] | m[3];
-            if (!any_mask) { popped = true; break; }
-            // order by the entry distances of the first lane that reaches anything (wave-uniform keys); children nobody reaches last
-            float key[4];
-#if defined(__HIP_DEVICE_COMPILE__)
-            const int lead = __builtin_ctzll(any_mask);
-#pragma unroll
-            for (int ch = 0; ch < 4; ch++) key[ch] = m[ch] ? __builtin_amdgcn_readlane(t[ch], lead) : INFINITY;
-#pragma unroll
-            for (int ch = 0; ch < 4; ch++) if (m[ch] && !(key[ch] < INFINITY)) key[ch] = 3.0e38f;  // reached by others, not by the lead lane: after its own
-#else
-            for (int ch = 0; ch < 4; ch++) key[ch] = t[ch];
-#endif
-#define PT_USWAP(i, j) do { if (key[j] < key[i]) { const float tk_ = key[i]; key[i] = key[j]; key[j] = tk_; const uint32_t tc_ = c[i]; c[i] = c[j]; c[j] = tc_; } } while (0)
-            PT_USWAP(0, 1); PT_USWAP(2, 3); PT_USWAP(0, 2); PT_USWAP(1, 3); PT_USWAP(1, 2);
-#undef PT_USWAP
-            const int hits = (key[1] < INFINITY) + (key[2] < INFINITY) + (key[3] < INFINITY);
-            if (sp + hits > words) { overflowed(); return; }
-            if (key[3] < INFINITY) { slot(sp) = c[3]; sp++; }
-            if (key[2] < INFINITY) { slot(sp) = c[2]; sp++; }
-            if (key[1] < INFINITY) { slot(sp) = c[1]; sp++; }
-            cur = c[0];
-        }
-#else
         while (!(cur & PT_REF_LEAF)) {
             const pt_u32x16 v = pt_sload16(sc.bvh + cur);
             const bool mine = alive && part;
