@@ -965,6 +965,7 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     for (;;) {
         while (!(cur & PT_REF_LEAF)) {
             const pt_u32x16 v = pt_sload16(sc.bvh + cur);
+            PT_WAVE_COUNT(4);
             const bool mine = alive && (!STATS || (in & self));
             if (STATS && mine) cnt->n_inner++;
             float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;  // rounded up, like the per-lane walk
@@ -1003,6 +1004,7 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
             }
         }
         const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+        PT_WAVE_COUNT(5);
         for (uint32_t i = 0; i < count; i++) {
             const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
             if (alive && (!STATS || (in & self))) {
@@ -1051,6 +1053,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
         bool popped = false;
         while (!(cur & PT_REF_LEAF)) {
             const pt_u32x16 v = pt_sload16(sc.bvh + cur);
+            PT_WAVE_COUNT(4);
             const bool mine = alive && part;
             if (STATS && mine) cnt->n_inner++;
             float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;
@@ -1078,6 +1081,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
         }
         if (!popped) {
             const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+            PT_WAVE_COUNT(5);
             if (STATS && alive && part) cnt->n_leaf++;
             if (inst != PT_NO_HIT) {  // triangles of the mesh being walked
                 for (uint32_t i = 0; i < count; i++) {
