@@ -217,6 +217,23 @@ PT_HD uint32_t pt_lane_sample(const PtRenderArgs& a, uint32_t item) {
     return it.sample;
 }
 
+// -DPT_XY_ON_DEMAND: the pixel coordinates too (experiment; see profiles/r02/notes.md)
+PT_HD void pt_lane_xy(const PtRenderArgs& a, uint32_t item, uint32_t* x, uint32_t* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(item));
+    const uint32_t lane = threadIdx.x & 63u;
+#else
+    const uint32_t lane = 0;
+#endif
+    PtItemLane it;
+    pt_item_lane(a, item, lane, &it, x, y);
+}
+#ifdef PT_XY_ON_DEMAND
+#define PT_LANE_XY(a, L, X, Y) uint32_t X, Y; pt_lane_xy(a, (L).item, &X, &Y)
+#else
+#define PT_LANE_XY(a, L, X, Y) const uint32_t X = (L).x, Y = (L).y
+#endif
+
 PT_HD PtVec3 pt_background(const PtRenderArgs& a, uint32_t x, uint32_t y) {  // render.rs:31-34
     const double* b = a.background_rows ? a.background + 3 * (size_t)y : a.background + 3 * ((size_t)y * a.width + x);
     return pt_v3(b[0], b[1], b[2]);
@@ -299,7 +316,8 @@ PT_HD PtVec3 pt_light_position(const PtRenderArgs& a, const PtLane& L, const dou
     *is_area = !empty;
     if (empty) return pos;
     const uint32_t sample = pt_lane_sample(a, L.item);
-    uint64_t pixel = (uint64_t)L.y * a.width + L.x;
+    PT_LANE_XY(a, L, lx, ly);
+    uint64_t pixel = (uint64_t)ly * a.width + lx;
     double a_coord = 2.0 * pt_rng_f64(a.seed, pixel, sample, draw0) - 1.0;
     double b_coord = 2.0 * pt_rng_f64(a.seed, pixel, sample, draw0 + 1) - 1.0;
     return pos + (aa * a_coord + ab * b_coord);
@@ -492,14 +510,15 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         case PT_ST_NEW_SAMPLE: {
             PT_FENCE;
             double jx = 0.5, jy = 0.5;
+            PT_LANE_XY(a, L, lx, ly);
             if (a.jitter_mode == PT_JITTER_RNG) {  // render.rs:38-39: x drawn before y
                 const uint32_t sample = pt_lane_sample(a, L.item);
-                uint64_t pixel = (uint64_t)L.y * a.width + L.x;
+                uint64_t pixel = (uint64_t)ly * a.width + lx;
                 jx = pt_rng_f64(a.seed, pixel, sample, 0);
                 jy = pt_rng_f64(a.seed, pixel, sample, 1);
             }
             L.draw = 2;
-            L.ray = pt_camera_ray(a.cam, (double)L.x + jx, (double)L.y + jy);
+            L.ray = pt_camera_ray(a.cam, (double)lx + jx, (double)ly + jy);
             L.depth = 0;
             if (PARK > 0) L.lo = 0;
             L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
@@ -508,7 +527,7 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         }
         case PT_ST_CLOSEST_DONE: {  // ray.rs:139-148
             PT_FENCE;
-            if (hit.node == PT_NO_HIT) { value = pt_background(a, L.x, L.y); returning = true; continue; }
+            if (hit.node == PT_NO_HIT) { PT_LANE_XY(a, L, lx, ly); value = pt_background(a, lx, ly); returning = true; continue; }
             if (STATS) cnt->hits++;
             // flat_scene.rs:85-95: rebuild the model-space hit, bring point and normal to world space
             const uint32_t* info = sc.info + 4 * (size_t)hit.node;
@@ -638,7 +657,8 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 PtVec3 u_basis = pt_cross(reflect_dir, off);
                 PtVec3 v_basis = pt_cross(reflect_dir, u_basis);
                 const uint32_t sample = pt_lane_sample(a, L.item);
-                uint64_t pixel = (uint64_t)L.y * a.width + L.x;
+                PT_LANE_XY(a, L, lx, ly);
+                uint64_t pixel = (uint64_t)ly * a.width + lx;
                 double u_coord = -glossy / 2.0 + pt_rng_f64(a.seed, pixel, sample, L.draw) * glossy;
                 double v_coord = -glossy / 2.0 + pt_rng_f64(a.seed, pixel, sample, L.draw + 1) * glossy;
                 L.draw += 2;
@@ -665,7 +685,8 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             }
             if (L.depth + 1 > PT_MAX_DEPTH) {  // depth-11 rays: their colour is always the background (material.rs:102-104), not traced
                 if (STATS) cnt->depth11_skipped++;
-                PtVec3 bg = pt_background(a, L.x, L.y);
+                PT_LANE_XY(a, L, lx, ly);
+                PtVec3 bg = pt_background(a, lx, ly);
                 if (!have) {
                     value = color + bg * reflectivity;
                 } else {
