@@ -11,8 +11,11 @@
 //    (or a compact window of a few), which is what keeps its lanes in step inside the walk (profiles/r02/notes.md).
 //  * one traversal loop per wavefront for all ray kinds: pt_lane_advance() turns whatever the lane traced
 //    last into its next ray, so secondary rays re-enter the same loop instead of recursing.
-//  * per-lane LDS columns: the traversal stack (32-bit words, overflowing to HBM beyond the LDS part) and
-//    the frame of the hit being shaded (doubles). Recursion frames go to HBM only when a hit spawns a child.
+//  * in the flat_scene and hierarchical semantics the trees are walked ONCE PER WAVEFRONT (pt_trace.h: pt_trace_packet,
+//    pt_trace_packet_mesh): node index and stack are scalars, nodes and leaf records come through the scalar cache; the
+//    k-d tree semantics keep a walk per lane.
+//  * LDS: the traversal stack (the wavefront's, or one column per lane, overflowing to HBM beyond the LDS part), per lane the
+//    frame of the hit being shaded and - scenes with reflective materials - its youngest parked recursion frame.
 //  * the chunk's samples are added in ascending order by the lane of the pixel's first sample, reading its
 //    neighbours' finished colours from LDS; pt_finish_kernel adds the chunk sums in order.
 #pragma once
