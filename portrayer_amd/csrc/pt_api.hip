@@ -179,6 +179,7 @@ struct pt_context {
     PtBuf spill, stack_spill, accum, bg, rgb, linear, misc;  // misc: work counter + overflow flag (8 B), PtCounters at +256
     bool needs_spill = false;  // some material is reflective (recursion frames) or the scene has more than 32 lights
     bool spawns = false;       // some material is reflective: hits spawn rays, so the cost of a pixel varies by orders of magnitude
+    bool four_waves = false;   // traversal-heavy scene without reflective materials, flat_scene / hierarchical semantics: the 4-waves-per-SIMD kernel
     PtSceneView view;
     bool have_scene = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -651,6 +652,16 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     c->needs_spill = s->n_lights > PT_LIGHT_ROUND;
     c->spawns = false;
     for (uint32_t m = 0; m < s->n_materials; m++) if (mats[10 * (size_t)m + 7] > 0.0) c->needs_spill = c->spawns = true;  // material.rs:216: reflectivity > 0 spawns children
+    // The 4-waves-per-SIMD kernel for scenes where the tree walk outweighs the shading: many scene-level nodes or many instanced
+    // triangles, nothing reflective, flat_scene semantics (measured: big-scene +8.7 %, big-soup +6.8 %; macho-cows
+    // with its 23 nodes and 17,500 triangles -8 %; reflective scenes and the k-d walk lose, profiles/r02/notes.md)
+    {
+        uint64_t instanced_tris = 0;
+        for (uint32_t i = 0; i < n; i++)
+            if (s->prim_type[i] == PT_PRIM_MESH || s->prim_type[i] == PT_PRIM_KDMESH) instanced_tris += s->mesh_tri_off[s->prim_data[i] + 1] - s->mesh_tri_off[s->prim_data[i]];
+        // hierarchical semantics: big-scene measured 2 % slower at 4 waves, the 1.25 M-triangle soup 4 % faster
+        c->four_waves = !c->spawns && ((traverse == PT_TRAVERSE_FLAT && (n >= 256 || instanced_tris >= 65536)) || (traverse == PT_TRAVERSE_HIER && instanced_tris >= 65536));
+    }
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
     if ((rc = pt_upload(c, c->materials, mats)) || (rc = pt_upload(c, c->lights, lights))) return rc;
 
@@ -792,17 +803,17 @@ static int pt_check_params(pt_context* c, const pt_camera* cam, const pt_render_
     return PT_OK;
 }
 
-// a.park_slots (0 / 1) selects the instantiation without / with a parked recursion frame in LDS.
+// a.park_slots / a.four_waves select the instantiation: 1 with a parked recursion frame in LDS, 2 for 4 waves per SIMD, 0 neither.
 static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
     const bool tex = a.scene.mat_maps != nullptr;
     switch (a.scene.mode) {
-    case PT_MODE_KD: return pt_launch_mode_2(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_FLAT_NOMESH: return pt_launch_mode_3(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_FLAT_KDMESH: return pt_launch_mode_4(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_HIER: return pt_launch_mode_5(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
-    default: return pt_launch_mode_1(a, a.park_slots, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_KD: return pt_launch_mode_2(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_FLAT_NOMESH: return pt_launch_mode_3(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_FLAT_KDMESH: return pt_launch_mode_4(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER: return pt_launch_mode_5(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
+    default: return pt_launch_mode_1(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
     }
 }
 
@@ -847,7 +858,9 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.park_slots = 1;
     if (const char* e = getenv("PORTRAYER_PARK")) a.park_slots = atoi(e) > 0 ? 1 : 0;  // 0: every parked frame in HBM (tests, measurements)
     if (!c->spawns) a.park_slots = 0;
-    size_t block_budget = 52 * 1024;  // 3 x 52 KB of the CU's 160 KB
+    a.four_waves = (!a.park_slots && c->four_waves) ? 1 : 0;
+    if (const char* e = getenv("PORTRAYER_WAVES")) a.four_waves = (!a.park_slots && atoi(e) == 4) ? 1 : 0;
+    size_t block_budget = a.four_waves ? 39 * 1024 : 52 * 1024;  // 3 x 52 KB or 4 x 39 KB of the CU's 160 KB
     if (const char* e = getenv("PORTRAYER_LDS_BUDGET_KB")) block_budget = (size_t)std::max(16, std::min(160, atoi(e))) * 1024;  // experiment: 80 = two blocks per CU
     const size_t frame_bytes = (size_t)(PT_LDS_FRAME_F64 + a.park_slots * PT_PARK_F64) * PT_BLOCK * 8;
     int lds_cap = block_budget > frame_bytes ? (int)((block_budget - frame_bytes) / (PT_BLOCK * 4)) : 0;

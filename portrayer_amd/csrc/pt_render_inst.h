@@ -8,7 +8,7 @@
 #include "pt_shade.h"
 
 #define PT_DECLARE_MODE_LAUNCHER(n) \
-    hipError_t pt_launch_mode_##n(const PtRenderArgs& a, int park, bool stats, bool tex, int n_cu, hipStream_t stream, uint32_t* grid, bool launch)
+    hipError_t pt_launch_mode_##n(const PtRenderArgs& a, int variant, bool stats, bool tex, int n_cu, hipStream_t stream, uint32_t* grid, bool launch)
 PT_DECLARE_MODE_LAUNCHER(1);  // PT_MODE_FLAT
 PT_DECLARE_MODE_LAUNCHER(2);  // PT_MODE_KD
 PT_DECLARE_MODE_LAUNCHER(3);  // PT_MODE_FLAT_NOMESH

@@ -1,5 +1,5 @@
 // One traversal mode's instantiations of pt_render_kernel (counting / plain, textured / untextured,
-// with / without a parked recursion frame in LDS) and their launcher. Compiled once per mode: -DPT_INST_MODE=1..7 (Makefile).
+// the three variants of pt_render_kernel.h) and their launcher. Compiled once per mode: -DPT_INST_MODE=1..7 (Makefile).
 #include "pt_render_kernel.h"
 #include "pt_render_inst.h"
 
@@ -9,8 +9,11 @@
 #define PT_INST_CAT2(a, b) a##b
 #define PT_INST_CAT(a, b) PT_INST_CAT2(a, b)
 
-hipError_t PT_INST_CAT(pt_launch_mode_, PT_INST_MODE)(const PtRenderArgs& a, int park, bool stats, bool tex, int n_cu, hipStream_t stream,
+hipError_t PT_INST_CAT(pt_launch_mode_, PT_INST_MODE)(const PtRenderArgs& a, int variant, bool stats, bool tex, int n_cu, hipStream_t stream,
                                                       uint32_t* grid, bool launch) {
-    return park ? pt_dispatch_variant<PT_INST_MODE, 1>(a, stats, tex, n_cu, stream, grid, launch)
-                : pt_dispatch_variant<PT_INST_MODE, 0>(a, stats, tex, n_cu, stream, grid, launch);
+    if (variant == 1) return pt_dispatch_variant<PT_INST_MODE, 1>(a, stats, tex, n_cu, stream, grid, launch);
+#if PT_INST_MODE != 2 && PT_INST_MODE != 7  // the k-d tree semantics (per-lane walk) have no 4-wave instantiation: measured slower there
+    if (variant == 2) return pt_dispatch_variant<PT_INST_MODE, 2>(a, stats, tex, n_cu, stream, grid, launch);
+#endif
+    return pt_dispatch_variant<PT_INST_MODE, 0>(a, stats, tex, n_cu, stream, grid, launch);
 }

@@ -27,13 +27,16 @@
 
 #include "pt_shade.h"
 
-// Waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument): 3 (168 VGPRs). 4 (128 VGPRs,
-// more spills) measured slower on every workload with this kernel (profiles/r02/notes.md) and is no longer built.
+// VAR (template parameter), chosen per scene in pt_scene_upload:
+//   0  hits never spawn rays; 3 waves per SIMD (168 VGPRs). The code and lane state for parked recursion frames are compiled out.
+//   1  scenes with reflective materials: the youngest parked recursion frame of a lane stays in LDS (PARK); 3 waves per SIMD.
+//   2  like 0 with 4 waves per SIMD (128 VGPRs): with the wave-uniform walk the traversal needs few registers of its own, and
+//      traversal-heavy scenes gain from the fourth wave (big-scene 19.1 -> 20.8 Gray/s, big-soup 6.9 -> 7.4) where shading-heavy
+//      and reflective ones lose (cows -8 %, mirror -7 %, transmission-refraction -21 %; profiles/r02/notes.md).
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 3  // experiments: -DPT_MIN_WAVES=2 / 4
+#define PT_MIN_WAVES 0  // experiments: -DPT_MIN_WAVES=2 / 3 / 4 for every instantiation
 #endif
-// PARK (template parameter): 1 = the youngest parked recursion frame of a lane stays in LDS (scenes with reflective
-// materials), 0 = scenes whose hits never spawn rays: the code and the lane state for it are compiled out.
+#define PT_VAR_WAVES(VAR) (PT_MIN_WAVES ? PT_MIN_WAVES : ((VAR) == 2 ? 4 : 3))
 
 __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCounters& c) {
     const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&c);
@@ -47,8 +50,9 @@ __host__ __device__ inline size_t pt_render_lds_bytes(int stack_lds_cap, bool te
     return (size_t)stack_lds_cap * PT_BLOCK * 4 + (size_t)(PT_LDS_FRAME_F64 + park_slots * PT_PARK_F64) * PT_BLOCK * 8;
 }
 
-template <int MODE, bool STATS, bool TEX, int PARK>
-__global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRenderArgs a) {
+template <int MODE, bool STATS, bool TEX, int VAR>
+__global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(PtRenderArgs a) {
+    constexpr int PARK = VAR == 1 ? 1 : 0;
     extern __shared__ uint32_t pt_lds[];
     const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
@@ -222,18 +226,18 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) pt_render_kernel(PtRen
 
 // Launch (or, with launch = false, only size) one instantiation. The grid is what is resident: blocks per CU from
 // the occupancy query for this kernel with its LDS.
-template <int MODE, bool STATS, bool TEX, int PARK>
+template <int MODE, bool STATS, bool TEX, int VAR>
 static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
-    size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, PARK);
+    size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, VAR == 1 ? 1 : 0);
     static size_t lds_allowed = 64 * 1024;  // per instantiation: raised once, not on every launch
     hipError_t e;
     if (lds > lds_allowed) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, PARK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_allowed = lds;
     }
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX, PARK>, PT_BLOCK, lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX, VAR>, PT_BLOCK, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     uint32_t want = (a.n_items + (PT_BLOCK / 64) - 1) / (PT_BLOCK / 64);
@@ -241,12 +245,12 @@ static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream,
     uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
     *grid_out = grid;
     if (!launch) return hipSuccess;
-    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, PARK>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, VAR>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int MODE, int PARK>
+template <int MODE, int VAR>
 static hipError_t pt_dispatch_variant(const PtRenderArgs& a, bool stats, bool tex, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
-    if (tex) return stats ? pt_launch<MODE, true, true, PARK>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true, PARK>(a, n_cu, stream, grid, launch);
-    return stats ? pt_launch<MODE, true, false, PARK>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false, PARK>(a, n_cu, stream, grid, launch);
+    if (tex) return stats ? pt_launch<MODE, true, true, VAR>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true, VAR>(a, n_cu, stream, grid, launch);
+    return stats ? pt_launch<MODE, true, false, VAR>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false, VAR>(a, n_cu, stream, grid, launch);
 }
