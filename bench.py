@@ -77,7 +77,13 @@ def measured_profile(workload, traversal, n_gpus):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             t = json.load(fh)
-        return t.get(f"{workload}/{traversal}/gpus{n_gpus}")
+        key = f"{workload}/{traversal}/gpus{n_gpus}"
+        waves = os.environ.get("PORTRAYER_WAVES")  # the kernel variant is part of what was profiled (profiles/r02/notes.md section 16)
+        if waves == "3":
+            return t.get(key + "/waves3") or (t.get(key) if "<1, " not in (t.get(key) or {}).get("kernel", "") and ", 2>" not in (t.get(key) or {}).get("kernel", "") else None)
+        if waves == "4" and ", 2>" not in (t.get(key) or {}).get("kernel", ""):
+            return None
+        return t.get(key)
     except (OSError, ValueError):
         return None
 
