@@ -78,12 +78,15 @@ def measured_profile(workload, traversal, n_gpus):
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             t = json.load(fh)
         key = f"{workload}/{traversal}/gpus{n_gpus}"
-        waves = os.environ.get("PORTRAYER_WAVES")  # the kernel variant is part of what was profiled (profiles/r02/notes.md section 16)
+        entry = t.get(key)
+        # the kernel variant is part of what was profiled (profiles/r02/notes.md section 16): instantiation "..., 2>" = 4 waves per SIMD
+        four = entry is not None and ", 2>" in entry.get("kernel", "")
+        waves = os.environ.get("PORTRAYER_WAVES")
         if waves == "3":
-            return t.get(key + "/waves3") or (t.get(key) if "<1, " not in (t.get(key) or {}).get("kernel", "") and ", 2>" not in (t.get(key) or {}).get("kernel", "") else None)
-        if waves == "4" and ", 2>" not in (t.get(key) or {}).get("kernel", ""):
-            return None
-        return t.get(key)
+            return t.get(key + "/waves3") if four else entry
+        if waves == "4":
+            return entry if four else None
+        return entry
     except (OSError, ValueError):
         return None
 
