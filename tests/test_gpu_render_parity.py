@@ -503,12 +503,14 @@ def test_traversal_stack_beyond_lds_gives_the_same_image(host, H, monkeypatch, n
 
 @pytest.mark.parametrize("env", [{"PORTRAYER_COLLAPSE": "plain"}, {"PORTRAYER_COLLAPSE": "area"}, {"PORTRAYER_FINE_QUEUES": "0"}, {"PORTRAYER_FINE_QUEUES": "1"},
                                  {"PORTRAYER_FINE_QUEUES": "64"}, {"PORTRAYER_FINE_QUEUES": "0", "PORTRAYER_BATCH_MAX": "1"},
-                                 {"PORTRAYER_FINE_QUEUES": "0", "PORTRAYER_ITEM_STRIDE": "golden"}, {"PORTRAYER_LANE_CHUNKS": "1"}])
-@pytest.mark.parametrize("name,mode", [("entering-the-mirror-dimension", "flat"), ("macho-cows", "hier")])
+                                 {"PORTRAYER_FINE_QUEUES": "0", "PORTRAYER_ITEM_STRIDE": "golden"}, {"PORTRAYER_LANE_CHUNKS": "1"},
+                                 {"PORTRAYER_WAVES": "4"}, {"PORTRAYER_WAVES": "3"}])
+@pytest.mark.parametrize("name,mode", [("entering-the-mirror-dimension", "flat"), ("macho-cows", "hier"), ("macho-cows", "flat"), ("primitives-simple", "flat")])
 def test_scheduling_and_tree_shape_do_not_change_the_image(host, H, monkeypatch, name, mode, env):
     """How work items are handed out (guided batches, interleaved single-item queues, a scattered order), how many chunks of a
-    pixel a wavefront runs side by side and which four-child form the trees take are performance choices with defaults picked
-    per scene; every other setting must give the same image, linear values and ray counts."""
+    pixel a wavefront runs side by side, which four-child form the trees take and whether the kernel is the 168- or the
+    128-register build (3 / 4 waves per SIMD; small scenes get 3 by default) are performance choices with defaults picked per
+    scene; every other setting must give the same image, linear values and ray counts."""
     scene = host.Scene.example(name)
     tr = H.TRAVERSE_FLAT if mode == "flat" else H.TRAVERSE_HIER
     w, h = 203, 117
