@@ -821,10 +821,21 @@ PT_HD bool pt_trace_kd(const PtSceneView& sc, const PtRay& ray, bool any, PtHit&
 typedef uint32_t pt_u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t pt_u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
+// A wave-uniform address as the scalar-register pair the s_load instructions need, wherever the compiler chose to compute it
+// (an inline-asm "s" operand that arrives in vector registers is a build error, not a copy).
+PT_HD const void* pt_uniform_ptr(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned long long lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return (const void*)((hi << 32) | lo);
+#else
+    return p;
+#endif
+}
 PT_HD pt_u32x16 pt_sload16(const void* p) {
     pt_u32x16 v;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pt_uniform_ptr(p)) : "memory");
 #else
     v = *static_cast<const pt_u32x16*>(p);
 #endif
@@ -833,7 +844,7 @@ PT_HD pt_u32x16 pt_sload16(const void* p) {
 PT_HD pt_u32x8 pt_sload8(const void* p) {
     pt_u32x8 v;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pt_uniform_ptr(p)) : "memory");
 #else
     v = *static_cast<const pt_u32x8*>(p);
 #endif
@@ -842,7 +853,7 @@ PT_HD pt_u32x8 pt_sload8(const void* p) {
 PT_HD pt_u32x4 pt_sload4(const void* p) {
     pt_u32x4 v;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pt_uniform_ptr(p)) : "memory");
 #else
     v = *static_cast<const pt_u32x4*>(p);
 #endif
@@ -874,7 +885,7 @@ PT_HD void pt_sload_mat12(const double* p, double m[12]) {
     pt_u32x16 a;
     pt_u32x8 b;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(p)) : "memory");
 #else
     a = *reinterpret_cast<const pt_u32x16*>(p);
     b = *reinterpret_cast<const pt_u32x8*>(reinterpret_cast<const char*>(p) + 64);
@@ -908,10 +919,10 @@ PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRa
     const void* rec = sc.inv + 12 * (size_t)node;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (HIER) {
-        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(info) : "s"(info_ptr) : "memory");
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(info) : "s"(pt_uniform_ptr(info_ptr)) : "memory");
     } else {
         asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(info), "=&s"(a), "=&s"(b) : "s"(info_ptr), "s"(rec) : "memory");
+                     : "=&s"(info), "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(rec)) : "memory");
     }
 #else
     info = *static_cast<const pt_u32x4*>(info_ptr);
@@ -1093,7 +1104,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                     {
                         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                         u32x2 b;
-                        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(rec) : "memory");
+                        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(rec)) : "memory");
                         b0 = b[0]; b1 = b[1];
                     }
 #else
