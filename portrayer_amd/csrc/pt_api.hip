@@ -876,7 +876,13 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // interleaved queues. transmission-refraction: wavefronts resident 47 % of the launch and 5.2 Gray/s with batches, 11+ without.
     a.batch_max = PT_WORK_BATCH_MAX;
     if (const char* e = getenv("PORTRAYER_BATCH_MAX")) a.batch_max = (uint32_t)std::max(1, atoi(e));
-    a.fine_queues = c->spawns ? PT_FINE_QUEUES : 0;
+    // The queues also win wherever a wavefront gets few items (a small frame, one GPU's share of a frame: big-scene's 1/8 share +8 %,
+    // macho-cows +13 %) and on the mesh-heavy scenes (+3-7 %); very long launches (> 2048 items per resident wavefront: 3840x2160x256)
+    // and the k-d tree semantics are 1 % better off with batches.
+    const uint64_t resident_waves = (uint64_t)grid * (PT_BLOCK / 64);
+    const bool long_launch = (uint64_t)a.n_items > 2048ull * std::max<uint64_t>(resident_waves, 1);
+    const bool kd_mode = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH;
+    a.fine_queues = (c->spawns || (!long_launch && !kd_mode)) ? PT_FINE_QUEUES : 0;
     if (const char* e = getenv("PORTRAYER_FINE_QUEUES")) a.fine_queues = (uint32_t)std::max(0, std::min(PT_FINE_QUEUES, atoi(e)));
     a.item_stride = 1;
     if (const char* e = getenv("PORTRAYER_ITEM_STRIDE")) {  // experiment (batches only): position q -> item (q * stride) mod n; "golden" = 0.618 n
