@@ -893,8 +893,8 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     int rc;
     const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_STRIDE * sizeof(double) : 16;
     if ((rc = pt_reserve(c, c->spill, spill_bytes))) return rc;
-    // + 4: the wavefront's own stack may take up to four of the LDS rows from the lanes' stacks (pt_render_kernel)
-    if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * (size_t)std::max(a.scene.stack_cap - a.stack_lds_cap + 4, 0) * 4))) return rc;
+    // + 8: the wavefront's own stack may take up to eight of the LDS rows from the lanes' stacks (pt_render_kernel)
+    if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * (size_t)std::max(a.scene.stack_cap - a.stack_lds_cap + 8, 0) * 4))) return rc;
     if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4))) return rc;
     if ((rc = pt_reserve(c, c->accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
     a.accum = (double*)c->accum.p;

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
                                                               a.overflow_flag, &cnt);
             } else if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
                 if (__any(tracing)) {
-                    const int rows = a.stack_lds_cap >= 16 ? 4 : (a.stack_lds_cap >= 4 ? 2 : 1);  // of the wavefront's stack; the lanes' own stacks get the rest
+                    const int rows = a.stack_lds_cap >= 16 ? 8 : (a.stack_lds_cap >= 8 ? 3 : (a.stack_lds_cap >= 4 ? 2 : 1));  // of the wavefront's stack (64 entries each); the lanes' own stacks get the rest
                     PtStackSpill lane_stk = stk;
                     lane_stk.cap = a.stack_lds_cap - rows;
                     pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, L.ray, tracing, L.ray_any, hit,
