@@ -253,6 +253,12 @@ int pt_measure_copy_bandwidth(pt_context *ctx, uint64_t bytes, int iters, double
 int pt_test_cast_rays(pt_context *ctx, uint64_t n, const double *origins, const double *directions, int any_hit,
                       double *out_t, int32_t *out_node, int32_t *out_sub);
 int pt_test_math(pt_context *ctx, int op, uint64_t n, const double *a, const double *b, double *out);
+/* Host-side replay (no GPU, no context) of how a launch with these parameters lays its work items and their 64 lanes over pixels,
+ * chunks and samples - the kernel's own indexing code. Arrays of width x height, zeroed by the caller: samples carried per pixel,
+ * the sum of their indices, the sum of the chunk lengths reported by the lanes that add a chunk up; optionally the number of work
+ * items and {pixels, chunks, samples} per wavefront. */
+int pt_test_work_items(const pt_render_params *params, uint32_t *sample_count, uint64_t *sample_index_sum, uint32_t *chunk_length_sum,
+                       uint64_t *n_items, uint32_t *lane_pixels_chunks_samples);
 
 #ifdef __cplusplus
 }

@@ -88,7 +88,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = ["pt_abi_version", "pt_device_count", "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_scene_upload",
            "pt_render", "pt_render_device", "pt_render_finish", "pt_compact_bytes", "pt_untile_device", "pt_tile_slot_pixel", "pt_untile_host", "pt_device_alloc",
            "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_synchronize", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
-           "pt_test_math", "pt_node_create", "pt_node_destroy", "pt_node_last_error", "pt_node_ranks", "pt_node_uses_rccl", "pt_node_context",
+           "pt_test_math", "pt_test_work_items", "pt_node_create", "pt_node_destroy", "pt_node_last_error", "pt_node_ranks", "pt_node_uses_rccl", "pt_node_context",
            "pt_node_scene_upload", "pt_node_render"]
 
 
@@ -150,6 +150,8 @@ def lib() -> C.CDLL:
         l.pt_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _dp]
         l.pt_test_cast_rays.restype = C.c_int
         l.pt_test_cast_rays.argtypes = [C.c_void_p, C.c_uint64, _dp, _dp, C.c_int, _dp, _ip, _ip]
+        l.pt_test_work_items.restype = C.c_int
+        l.pt_test_work_items.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         l.pt_test_math.restype = C.c_int
         l.pt_test_math.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _dp, _dp, _dp]
         l.pt_node_create.restype = C.c_int

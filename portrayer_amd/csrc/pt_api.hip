@@ -817,12 +817,9 @@ static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipSt
     }
 }
 
-static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_params* p, PtRenderArgs* a) {
-    memset(a, 0, sizeof *a);
-    a->scene = c->view;
-    for (int k = 0; k < 3; k++) a->cam.eye[k] = cam->eye[k];
-    for (int k = 0; k < 12; k++) a->cam.view_to_world[k] = cam->view_to_world[k];
-    a->cam.fov_factor = cam->fov_factor; a->cam.aspect = cam->aspect_ratio; a->cam.width = cam->width; a->cam.height = cam->height;
+// The part of the kernel arguments that follows from the render parameters alone: the slice, the rank's tiles, how a wavefront's
+// 64 lanes are laid over pixels x chunks x samples, and the number of work items (pt_shade.h: pt_item_lane).
+static void pt_fill_work(const pt_render_params* p, PtRenderArgs* a) {
     a->background_rows = p->background_rows;
     a->width = p->width; a->height = p->height;
     a->x0 = p->slice.x0; a->y0 = p->slice.y0; a->x1 = p->slice.x1; a->y1 = p->slice.y1;
@@ -846,6 +843,45 @@ static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_par
     if (const char* e = getenv("PORTRAYER_LANE_CHUNKS")) { uint32_t v = (uint32_t)atoi(e); if (k == PT_SAMPLE_CHUNK && (v == 1 || v == 2 || v == 4 || v == 8)) cc = v; }
     a->lane_chunks = cc;
     a->n_items = (a->n_slots / 64) * ((a->n_chunks + cc - 1) / cc) * (k * cc);
+}
+
+static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_params* p, PtRenderArgs* a) {
+    memset(a, 0, sizeof *a);
+    a->scene = c->view;
+    for (int k = 0; k < 3; k++) a->cam.eye[k] = cam->eye[k];
+    for (int k = 0; k < 12; k++) a->cam.view_to_world[k] = cam->view_to_world[k];
+    a->cam.fov_factor = cam->fov_factor; a->cam.aspect = cam->aspect_ratio; a->cam.width = cam->width; a->cam.height = cam->height;
+    pt_fill_work(p, a);
+    return PT_OK;
+}
+
+// Host-side replay of the kernel's work decomposition (no GPU involved): every work item of a launch with these parameters,
+// every lane of it, through the same pt_item_lane the kernel uses. Per pixel of the image: how many (lane, item) pairs carry a
+// sample of it, the sum of their sample indices, and the sum of the chunk lengths reported by the lanes that add a chunk up.
+// Tests check that every sample of every pixel of the rank's tiles is covered exactly once.
+extern "C" int pt_test_work_items(const pt_render_params* p, uint32_t* sample_count, uint64_t* sample_index_sum, uint32_t* chunk_length_sum,
+                                  uint64_t* n_items, uint32_t* lane_pixels_chunks_samples) {
+    if (!p || !sample_count || !sample_index_sum || !chunk_length_sum) return PT_ERR_ARGUMENT;
+    if (p->width == 0 || p->height == 0 || p->samples == 0 || p->tile_ranks == 0 || p->tile_rank >= p->tile_ranks) return PT_ERR_ARGUMENT;
+    if (p->slice.x0 >= p->width || p->slice.x1 >= p->width || p->slice.y0 >= p->height || p->slice.y1 >= p->height) return PT_ERR_SLICE;
+    PtRenderArgs a;
+    memset(&a, 0, sizeof a);
+    pt_fill_work(p, &a);
+    if (n_items) *n_items = a.n_items;
+    if (lane_pixels_chunks_samples) {
+        lane_pixels_chunks_samples[0] = 64u / (a.lane_samples * a.lane_chunks); lane_pixels_chunks_samples[1] = a.lane_chunks; lane_pixels_chunks_samples[2] = a.lane_samples;
+    }
+    for (uint32_t w = 0; w < a.n_items; w++)
+        for (uint32_t lane = 0; lane < 64; lane++) {
+            PtItemLane it;
+            uint32_t x, y;
+            if (!pt_item_lane(a, w, lane, &it, &x, &y)) continue;
+            if (x >= p->width || y >= p->height) return PT_ERR_TRAVERSAL;  // would write outside the image
+            const size_t px = (size_t)y * p->width + x;
+            sample_count[px]++;
+            sample_index_sum[px] += it.sample;
+            if (it.first) chunk_length_sum[px] += it.count;
+        }
     return PT_OK;
 }
 
