@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 5
+#define PT_ABI_VERSION 6
 
 /* enum Primitive, src/primitive.rs:67-81 */
 enum { PT_PRIM_SPHERE = 0, PT_PRIM_TRIANGLE = 1, PT_PRIM_MESH = 2, PT_PRIM_KDMESH = 3, PT_PRIM_PLANE = 4, PT_PRIM_CUBE = 5, PT_PRIM_CYLINDER = 6, PT_PRIM_CONE = 7 };
@@ -180,7 +180,17 @@ typedef struct {
     double kernel_ms;           /* device time of the render kernel (HIP events)                          */
     double total_ms;            /* upload of per-call inputs + kernel + read-back                         */
     uint64_t diag[8];           /* (ABI 5) lane-occupancy diagnostics of -DPT_DIAG builds (profiles/diag.sh); 0 otherwise */
+    uint32_t kernel_mode;       /* (ABI 6) which instantiation of the render kernel ran: PT_KERNEL_MODE_* ...                */
+    uint32_t kernel_variant;    /* ... and PT_KERNEL_* (tests assert that a timed configuration is the one they checked)    */
 } pt_stats;
+
+/* pt_stats.kernel_mode: the walk the kernel was compiled with */
+enum { PT_KERNEL_MODE_FLAT = 1, PT_KERNEL_MODE_KD = 2, PT_KERNEL_MODE_FLAT_NOMESH = 3, PT_KERNEL_MODE_FLAT_KDMESH = 4, PT_KERNEL_MODE_HIER = 5,
+       PT_KERNEL_MODE_HIER_NOMESH = 6, PT_KERNEL_MODE_KD_NOMESH = 7 };
+/* pt_stats.kernel_variant: bit 0-3 waves per SIMD the kernel was compiled for (3 or 4); PT_KERNEL_INTERPRETER: the per-lane
+ * interpreter that scenes with reflective materials need (material.rs:216-303), else the straight-line kernel; PT_KERNEL_PARK:
+ * a parked recursion frame per lane in LDS; PT_KERNEL_COUNTING: the counting build (collect_stats); PT_KERNEL_TEXTURED */
+enum { PT_KERNEL_WAVES_MASK = 15, PT_KERNEL_INTERPRETER = 16, PT_KERNEL_PARK = 32, PT_KERNEL_COUNTING = 64, PT_KERNEL_TEXTURED = 128 };
 
 int pt_abi_version(void);
 int pt_device_count(void);
@@ -238,6 +248,15 @@ int pt_node_scene_upload(pt_node *node, const pt_scene *scene, int traverse, con
  * stats: counters summed over the ranks, kernel_ms of the slowest rank, total_ms of the whole call. */
 int pt_node_render(pt_node *node, const pt_camera *camera, const double *background, const pt_render_params *params,
                    uint8_t *rgb, pt_stats *stats);
+/* (ABI 6) The same call in its three parts, for callers that render many frames of one size (and for measuring the frame with its
+ * inputs resident in HBM): pt_node_upload_background copies the background to every rank (and, when rgb is not NULL, the
+ * caller's image to rank 0, so that pixels outside the slice keep their bytes); pt_node_render_resident renders, gathers and
+ * untiles into the image resident on rank 0 and returns when it is complete - no host buffer is touched; pt_node_download_image
+ * copies that image out. pt_node_device: the device index of a rank (< 0: no such rank). */
+int pt_node_upload_background(pt_node *node, const double *background, const pt_render_params *params, const uint8_t *rgb);
+int pt_node_render_resident(pt_node *node, const pt_camera *camera, const pt_render_params *params, pt_stats *stats);
+int pt_node_download_image(pt_node *node, const pt_render_params *params, uint8_t *rgb);
+int pt_node_device(const pt_node *node, int rank);
 
 /* Device-side helpers used by the measurement harness. */
 int pt_device_alloc(pt_context *ctx, uint64_t bytes, void **out);
@@ -253,6 +272,9 @@ int pt_measure_copy_bandwidth(pt_context *ctx, uint64_t bytes, int iters, double
 int pt_test_cast_rays(pt_context *ctx, uint64_t n, const double *origins, const double *directions, int any_hit,
                       double *out_t, int32_t *out_node, int32_t *out_sub);
 int pt_test_math(pt_context *ctx, int op, uint64_t n, const double *a, const double *b, double *out);
+/* (ABI 6) No GPU, no context: x[i]^y[i] by the HOST build of the kernels' pow (csrc/pt_pow.h) in `port` and by this machine's
+ * libm in `libm` - the pin of the restated glibc algorithm against the library the reference calls. */
+int pt_test_pow_host(uint64_t n, const double *x, const double *y, double *port, double *libm);
 /* Host-side replay (no GPU, no context) of how a launch with these parameters lays its work items and their 64 lanes over pixels,
  * chunks and samples - the kernel's own indexing code. Arrays of width x height, zeroed by the caller: samples carried per pixel,
  * the sum of their indices, the sum of the chunk lengths reported by the lanes that add a chunk up; optionally the number of work

@@ -75,7 +75,7 @@ class PtRenderParams(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("primary", "shadow", "reflect", "refract", "depth11_skipped", "hits", "n_inner", "n_leaf",
                                           "n_analytic", "n_tri", "n_bbox", "kd_plane_miss", "stack_overflow")] + \
-               [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("diag", C.c_uint64 * 8)]
+               [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("diag", C.c_uint64 * 8), ("kernel_mode", C.c_uint32), ("kernel_variant", C.c_uint32)]
 
     def as_dict(self):
         d = {n: (float if n.endswith("_ms") else int)(getattr(self, n)) for n, _ in self._fields_ if n != "diag"}
@@ -89,7 +89,8 @@ EXPORTS = ["pt_abi_version", "pt_device_count", "pt_context_create", "pt_context
            "pt_render", "pt_render_device", "pt_render_finish", "pt_compact_bytes", "pt_untile_device", "pt_tile_slot_pixel", "pt_untile_host", "pt_device_alloc",
            "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_synchronize", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
            "pt_test_math", "pt_test_work_items", "pt_node_create", "pt_node_destroy", "pt_node_last_error", "pt_node_ranks", "pt_node_uses_rccl", "pt_node_context",
-           "pt_node_scene_upload", "pt_node_render"]
+           "pt_node_scene_upload", "pt_node_render", "pt_node_upload_background", "pt_node_render_resident", "pt_node_download_image",
+           "pt_node_device", "pt_test_pow_host"]
 
 
 def header_functions():
@@ -170,6 +171,16 @@ def lib() -> C.CDLL:
         l.pt_node_scene_upload.argtypes = [C.c_void_p, C.POINTER(PtScene), C.c_int, C.POINTER(PtKdTree)]
         l.pt_node_render.restype = C.c_int
         l.pt_node_render.argtypes = [C.c_void_p, C.POINTER(PtCamera), _dp, C.POINTER(PtRenderParams), _u8p, C.POINTER(PtStats)]
+        l.pt_node_upload_background.restype = C.c_int
+        l.pt_node_upload_background.argtypes = [C.c_void_p, _dp, C.POINTER(PtRenderParams), _u8p]
+        l.pt_node_render_resident.restype = C.c_int
+        l.pt_node_render_resident.argtypes = [C.c_void_p, C.POINTER(PtCamera), C.POINTER(PtRenderParams), C.POINTER(PtStats)]
+        l.pt_node_download_image.restype = C.c_int
+        l.pt_node_download_image.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), _u8p]
+        l.pt_node_device.restype = C.c_int
+        l.pt_node_device.argtypes = [C.c_void_p, C.c_int]
+        l.pt_test_pow_host.restype = C.c_int
+        l.pt_test_pow_host.argtypes = [C.c_uint64, _dp, _dp, _dp, _dp]
         _lib = l
     return _lib
 

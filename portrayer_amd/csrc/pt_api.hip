@@ -48,10 +48,11 @@ __global__ void pt_math_kernel(int op, uint64_t n, const double* a, const double
     switch (op) {
     case 0: r = sqrt(a[i]); break;
     case 1: r = a[i] / b[i]; break;
-    case 2: r = pow(a[i], b[i]); break;
+    case 2: r = pt_pow(a[i], b[i]); break;  // the kernels' pow (pt_pow.h: glibc's, bit for bit)
     case 3: r = a[i] * b[i] + a[i]; break;  // must NOT be fused (-ffp-contract=off)
     case 4: r = atan2(a[i], b[i]); break;   // sphere.rs:57-58 (texture coordinates)
     case 5: r = acos(a[i]); break;          // sphere.rs:59
+    case 6: r = pow(a[i], b[i]); break;     // the device library's pow, for comparison
     default: r = 0.0; break;
     }
     out[i] = r;
@@ -185,6 +186,7 @@ struct pt_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool pending = false;
     bool pending_stats = false;
+    uint32_t last_mode = 0, last_variant = 0;  // pt_stats.kernel_mode / kernel_variant of the launch in flight
     std::chrono::steady_clock::time_point t_start;
 };
 
@@ -940,6 +942,10 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.overflow_flag = (unsigned int*)c->misc.p + 1;
     a.counters = (PtCounters*)((char*)c->misc.p + 256);
     a.work_queues = (unsigned int*)((char*)c->misc.p + 256 + sizeof(PtCounters));
+    c->last_mode = (uint32_t)a.scene.mode;
+    c->last_variant = (a.four_waves ? 4u : 3u) | (a.park_slots ? (PT_KERNEL_INTERPRETER | PT_KERNEL_PARK) : (pt_interpreter_forced() ? PT_KERNEL_INTERPRETER : 0u)) |
+                      (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
+    if ((a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH) && a.four_waves) c->last_variant = (c->last_variant & ~15u) | 3u;  // no 4-wave k-d instantiation
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
     if (a.n_items) {
@@ -971,6 +977,7 @@ static int pt_collect_stats(pt_context* c, pt_stats* st, bool counted) {
             for (int k = 0; k < 8; k++) st->diag[k] = h.diag[k];
         }
         if (head[1] && !st->stack_overflow) st->stack_overflow = 1;
+        st->kernel_mode = c->last_mode; st->kernel_variant = c->last_variant;
     }
     if (head[1]) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
     return PT_OK;
@@ -1208,6 +1215,12 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     unsigned int head[2] = {0, 0};
     PT_HIP(c, hipMemcpy(head, c->misc.p, sizeof head, hipMemcpyDeviceToHost));
     if (head[1]) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
+    return PT_OK;
+}
+
+extern "C" int pt_test_pow_host(uint64_t n, const double* x, const double* y, double* port, double* libm) {
+    if (!x || !y || !port || !libm) return PT_ERR_ARGUMENT;
+    for (uint64_t i = 0; i < n; i++) { port[i] = pt_pow_glibc(x[i], y[i]); libm[i] = pow(x[i], y[i]); }
     return PT_OK;
 }
 

@@ -96,11 +96,18 @@ PT_HD uint64_t pt_mix64(uint64_t z) {
     z ^= z >> 31;
     return z;
 }
-PT_HD double pt_rng_f64(uint64_t seed, uint64_t pixel, uint32_t sample, uint32_t draw) {
+// The generator in two steps: the key of a pixel (two of the three mixing rounds) and one draw from it. A lane that needs
+// several draws of the same pixel computes the key once.
+PT_HD uint64_t pt_rng_key(uint64_t seed, uint64_t pixel) {
     uint64_t k = pt_mix64(seed + 0x9e3779b97f4a7c15ULL);
-    k = pt_mix64(k ^ (pixel * 0xd1342543de82ef95ULL + 0x632be59bd9b4e019ULL));
-    k = pt_mix64(k ^ (((uint64_t)sample << 32) | (uint64_t)draw));
+    return pt_mix64(k ^ (pixel * 0xd1342543de82ef95ULL + 0x632be59bd9b4e019ULL));
+}
+PT_HD double pt_rng_draw(uint64_t key, uint32_t sample, uint32_t draw) {
+    uint64_t k = pt_mix64(key ^ (((uint64_t)sample << 32) | (uint64_t)draw));
     return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+}
+PT_HD double pt_rng_f64(uint64_t seed, uint64_t pixel, uint32_t sample, uint32_t draw) {
+    return pt_rng_draw(pt_rng_key(seed, pixel), sample, draw);
 }
 
 // Smallest double above a positive finite t (used to admit t == t_best for the index tie-break).

@@ -224,29 +224,56 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
     if (STATS) pt_flush_counters(a.counters, cnt);
 }
 
+#include "pt_render_simple.h"
+
 // Launch (or, with launch = false, only size) one instantiation. The grid is what is resident: blocks per CU from
-// the occupancy query for this kernel with its LDS.
-template <int MODE, bool STATS, bool TEX, int VAR>
-static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
-    size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, VAR == 1 ? 1 : 0);
-    static size_t lds_allowed = 64 * 1024;  // per instantiation: raised once, not on every launch
-    hipError_t e;
-    if (lds > lds_allowed) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_render_kernel<MODE, STATS, TEX, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_allowed = lds;
-    }
-    int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_render_kernel<MODE, STATS, TEX, VAR>, PT_BLOCK, lds);
+// the occupancy query for this kernel with its LDS. The raised LDS limit and the occupancy are properties of (kernel, device):
+// kept per device, so that one process can drive several GPUs (pt_node).
+#define PT_MAX_DEVICES 64
+template <class Kernel>
+static hipError_t pt_launch_kernel(Kernel kernel, size_t lds, const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
+    struct PerDevice { size_t lds_allowed = 64 * 1024; size_t occ_lds = ~(size_t)0; int per_cu = 0; };
+    static PerDevice state[PT_MAX_DEVICES];  // one per instantiation (this function is a template) and device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    PerDevice local;
+    PerDevice& st = (dev >= 0 && dev < PT_MAX_DEVICES) ? state[dev] : local;
+    if (lds > st.lds_allowed) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        st.lds_allowed = lds;
+    }
+    if (st.occ_lds != lds) {
+        int per_cu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PT_BLOCK, lds);
+        if (e != hipSuccess) return e;
+        st.per_cu = per_cu < 1 ? 1 : per_cu;
+        st.occ_lds = lds;
+    }
+    int per_cu = st.per_cu;
     uint32_t want = (a.n_items + (PT_BLOCK / 64) - 1) / (PT_BLOCK / 64);
     if (const char* env = getenv("PORTRAYER_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(env)));  // experiment: fewer resident lanes
     uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
     *grid_out = grid;
     if (!launch) return hipSuccess;
-    hipLaunchKernelGGL((pt_render_kernel<MODE, STATS, TEX, VAR>), dim3(grid), dim3(PT_BLOCK), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PT_BLOCK), lds, stream, a);
     return hipGetLastError();
+}
+
+// VAR 1 (reflective scenes) is the interpreter kernel; VAR 0 / 2 (hits spawn nothing; 3 / 4 waves per SIMD) the straight-line
+// kernel of pt_render_simple.h. -DPT_KEEP_INTERP also builds the interpreter for VAR 0 / 2 (PORTRAYER_INTERP=1 selects it: A/B runs).
+template <int MODE, bool STATS, bool TEX, int VAR>
+static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
+    const size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, VAR == 1 ? 1 : 0);
+    if constexpr (VAR == 1) {
+        return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, VAR>, lds, a, n_cu, stream, grid_out, launch);
+    } else {
+#ifdef PT_KEEP_INTERP
+        if (pt_interpreter_forced()) return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, VAR>, lds, a, n_cu, stream, grid_out, launch);
+#endif
+        return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, PT_VAR_WAVES(VAR)>, lds, a, n_cu, stream, grid_out, launch);
+    }
 }
 
 template <int MODE, int VAR>

@@ -1,0 +1,224 @@
+// The render kernel for scenes whose hits spawn no rays (no reflective material: material.rs:216 never takes the branch) -
+// render.rs:127-150 and everything below it as ONE straight line per work item, no interpreter:
+//
+//     primary ray (camera.rs:48-84)  ->  nearest hit  ->  surface + material (flat_scene.rs:85-95, material.rs:109-144)
+//     for every light in order (material.rs:149-210):  shadow ray -> any hit ? nothing : colour += (diffuse + specular) / attenuation
+//     -> the sample's colour (ray.rs:139-148), summed with its chunk (the summation contract, pt_shade.h)
+//
+// Without recursion every sample of a work item goes through the same sequence of rays, so the 64 lanes of a wavefront stay in
+// step by construction: what pt_lane_advance() (pt_shade.h, still the kernel of reflective scenes) does with a stage word, a
+// dispatch loop and a frame in LDS per lane is here plain control flow, and a light's direction and distance are worked out once -
+// for the shadow ray - and used again for the shading term (the interpreter recomputed them in its SHADE stage: the same
+// expressions, so the same bits). The light record is wave-uniform and comes through the scalar cache.
+//
+// Registers: nothing but the accumulated colour, the distance to the light and the material tag is live across a shadow ray's
+// walk besides the ray itself (the ray's origin IS the hit point, its direction IS the light direction); the shading normal and
+// the incoming direction wait in the lane's LDS column.
+#pragma once
+
+#include "pt_shade.h"
+
+// doubles at a wave-uniform address through the scalar cache (N = 2 or 4)
+template <int N>
+PT_HD void pt_sload_f64(const double* p, double* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (N == 4) {
+        pt_u32x8 v = pt_sload8(p);
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[k] = pt_f64_of(v[2 * k], v[2 * k + 1]);
+    } else {
+        pt_u32x4 v = pt_sload4(p);
+#pragma unroll
+        for (int k = 0; k < 2; k++) out[k] = pt_f64_of(v[2 * k], v[2 * k + 1]);
+    }
+#else
+    for (int k = 0; k < N; k++) out[k] = p[k];
+#endif
+}
+
+// One ray kind for the whole wavefront: `tracing` lanes carry `ray`; result in `hit` (untouched for the other lanes).
+template <int MODE, bool STATS>
+PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, bool any, PtHit& hit, const PtStackSpill& stk, uint32_t* lds, PtCounters* cnt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t* wave_lds = lds + (threadIdx.x & ~63u);
+#else
+    uint32_t* wave_lds = lds;
+#endif
+#ifndef PT_NO_PACKET
+    if (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) {
+        pt_trace_packet<STATS, MODE == PT_MODE_HIER_NOMESH>(a.scene, ray, tracing, any, hit, wave_lds, a.stack_lds_cap, a.overflow_flag, cnt);
+    } else if (MODE == PT_MODE_FLAT) {
+        pt_trace_packet_mesh<STATS, false, false>(a.scene, ray, tracing, any, hit, wave_lds, a.stack_lds_cap, stk, a.overflow_flag, cnt);
+    } else if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
+        const int rows = a.stack_lds_cap >= 16 ? 8 : (a.stack_lds_cap >= 8 ? 3 : (a.stack_lds_cap >= 4 ? 2 : 1));  // of the wavefront's stack (64 entries each); the lanes' own stacks get the rest
+        PtStackSpill lane_stk = stk;
+        lane_stk.cap = a.stack_lds_cap - rows;
+        pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, ray, tracing, any, hit, wave_lds + (size_t)lane_stk.cap * PT_BLOCK, rows, lane_stk, a.overflow_flag, cnt);
+    } else
+#endif
+    if (tracing) pt_trace<MODE, STATS>(a.scene, ray, any, hit, stk, cnt);
+}
+
+template <int MODE, bool STATS, bool TEX, int WAVES>
+__global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRenderArgs a) {
+    constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH;
+    extern __shared__ uint32_t pt_lds[];
+    const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    const PtSceneView& sc = a.scene;
+    PtStackSpill stk;
+    stk.base = pt_lds + threadIdx.x;
+    stk.cap = a.stack_lds_cap;
+    stk.total = a.scene.stack_cap;
+    stk.gbase = a.stack_spill + lane_global;
+    stk.gstride = a.n_lanes;
+    stk.overflow = a.overflow_flag;
+    PtFrameRef fr;
+    fr.lds = reinterpret_cast<double*>(pt_lds + (size_t)a.stack_lds_cap * PT_BLOCK) + threadIdx.x;
+    fr.park = fr.lds;
+    fr.spill = nullptr;
+    fr.n_lanes = a.n_lanes;
+
+    PtCounters cnt;
+    if (STATS) memset(&cnt, 0, sizeof cnt);
+    unsigned q_next = 0, q_end = 0, q_seen = 0;  // the wavefront's private batch of items (wave-uniform), as in pt_render_kernel
+    if (a.fine_queues) q_next = blockIdx.x % a.fine_queues;
+
+    for (;;) {
+        unsigned w;
+        if (a.fine_queues == 0u) {  // guided batches from one counter (very long launches, the k-d tree semantics)
+            if (q_next == q_end) {
+                unsigned remaining = a.n_items > q_seen ? a.n_items - q_seen : 0u;
+                unsigned take = remaining / a.work_div;
+                take = take > a.batch_max ? a.batch_max : (take < 1u ? 1u : take);
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(a.work_counter, take);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                q_next = base; q_end = base + take; q_seen = q_end;
+            }
+            const unsigned q = q_next++;
+            if (q >= a.n_items) break;
+            w = a.item_stride == 1u ? q : (unsigned)(((unsigned long long)q * a.item_stride) % a.n_items);
+        } else {  // one item at a time from interleaved queues
+            for (;;) {
+                unsigned idx = 0;
+                if (lane == 0) idx = atomicAdd(a.work_queues + q_next * PT_QUEUE_STRIDE, 1u);
+                idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+                const unsigned long long pos = (unsigned long long)idx * a.fine_queues + q_next;
+                if (pos < a.n_items) { w = (unsigned)pos; q_end = 0; break; }
+                q_next = q_next + 1u == a.fine_queues ? 0u : q_next + 1u;
+                if (++q_end == a.fine_queues) { w = 0xFFFFFFFFu; break; }
+            }
+            if (w == 0xFFFFFFFFu) break;
+        }
+
+        // ---- the primary ray of this lane's sample (render.rs:36-41, camera.rs:48-84)
+        uint32_t x, y;
+        bool mine;
+        PtRay ray;
+        ray.o = ray.d = pt_v3(0.0, 0.0, 0.0);
+        {
+            PtItemLane it;
+            mine = pt_item_lane(a, w, lane, &it, &x, &y);
+            if (mine) {
+                double jx = 0.5, jy = 0.5;
+                if (a.jitter_mode == PT_JITTER_RNG) {  // render.rs:38-39: x drawn before y
+                    const uint64_t key = pt_rng_key(a.seed, (uint64_t)y * a.width + x);
+                    jx = pt_rng_draw(key, it.sample, 0);
+                    jy = pt_rng_draw(key, it.sample, 1);
+                }
+                ray = pt_camera_ray(a.cam, (double)x + jx, (double)y + jy);
+                if (STATS) cnt.primary++;
+            }
+        }
+        PtHit hit;
+        hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
+        pt_trace_wave<MODE, STATS>(a, ray, mine, false, hit, stk, pt_lds, &cnt);
+
+        // ---- ray.rs:139-148: the background where nothing was hit, else Material::hit_color (material.rs:91-243, never its recursive part)
+        const bool shaded = mine && hit.node != PT_NO_HIT;
+        PtVec3 value = pt_v3(0.0, 0.0, 0.0);
+        if (mine && !shaded) value = pt_background(a, x, y);
+        if (__any(shaded)) {
+            uint32_t mat = 0, ftag = 0;
+            PtRay sray;  // o = the hit point for every light; d = the direction to the light being tested
+            sray.o = sray.d = pt_v3(0.0, 0.0, 0.0);
+            PtVec3 color = pt_v3(0.0, 0.0, 0.0);
+            if (shaded) {
+                if (STATS) cnt.hits++;
+                PtVec3 N;
+                pt_hit_surface<TEX, HIER>(sc, ray, hit, &sray.o, &N, &mat, &ftag);
+                fr.set_l3(PT_L_N, N);
+                fr.set_l3(PT_L_D, ray.d);
+                const double* m = sc.materials + 10 * (size_t)mat;
+                PtVec3 kd = pt_v3(m[0], m[1], m[2]);
+                if (TEX && (ftag & PT_FS_TEXEL)) kd = pt_v3(sc.srgb_lut[ftag & 255u], sc.srgb_lut[(ftag >> 8) & 255u], sc.srgb_lut[(ftag >> 16) & 255u]);
+                color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * kd;  // material.rs:148
+            }
+            uint32_t draw = 2;  // the two jitter draws came first
+            for (uint32_t li = 0; li < sc.n_lights; li++) {  // material.rs:149-210, one light after the other
+                const double* light = sc.lights + 15 * (size_t)li;
+                double lp[4], la[2], lb[4];  // position (+ colour.x), area_a.xy, area_a.z + area_b
+                pt_sload_f64<4>(light, lp);
+                pt_sload_f64<2>(light + 9, la);
+                pt_sload_f64<4>(light + 11, lb);
+                PtVec3 lpos = pt_v3(lp[0], lp[1], lp[2]);
+                const PtVec3 aa = pt_v3(la[0], la[1], lb[0]), ab = pt_v3(lb[1], lb[2], lb[3]);
+                const bool area = !((aa.x == 0.0 && aa.y == 0.0 && aa.z == 0.0) || (ab.x == 0.0 && ab.y == 0.0 && ab.z == 0.0));  // light.rs:51-53 (wave-uniform)
+                double light_dist = 0.0;
+                if (shaded) {
+                    if (area) {  // light.rs:62-70, :87-90
+                        PtItemLane it;
+                        uint32_t x2, y2;
+                        pt_item_lane(a, w, lane, &it, &x2, &y2);
+                        const uint64_t key = pt_rng_key(a.seed, (uint64_t)y * a.width + x);
+                        double a_coord = 2.0 * pt_rng_draw(key, it.sample, draw) - 1.0;
+                        double b_coord = 2.0 * pt_rng_draw(key, it.sample, draw + 1) - 1.0;
+                        lpos = lpos + (aa * a_coord + ab * b_coord);
+                    }
+                    PtVec3 hit_to_light = lpos - sray.o;
+                    light_dist = pt_length(hit_to_light);
+                    sray.d = hit_to_light / light_dist;
+                    if (STATS) cnt.shadow++;
+                }
+                if (area) draw += 2;
+                PtHit sh;
+                sh.t = INFINITY; sh.node = PT_NO_HIT; sh.sub = 0;
+                pt_trace_wave<MODE, STATS>(a, sray, shaded, true, sh, stk, pt_lds, &cnt);  // material.rs:174-179 only asks whether anything is in the way
+                if (shaded && sh.node == PT_NO_HIT) {
+                    double lc[2], lf[4];  // colour.xy, colour.z + falloff
+                    pt_sload_f64<2>(light + 3, lc);
+                    pt_sload_f64<4>(light + 5, lf);
+                    const double* m = sc.materials + 10 * (size_t)mat;
+                    PtVec3 kd = pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
+                    if (TEX && (ftag & PT_FS_TEXEL)) kd = pt_v3(sc.srgb_lut[ftag & 255u], sc.srgb_lut[(ftag >> 8) & 255u], sc.srgb_lut[(ftag >> 16) & 255u]);
+                    color = color + pt_light_term(pt_v3(lc[0], lc[1], lf[0]), pt_v3(lf[1], lf[2], lf[3]), sray.d, light_dist, fr.l3(PT_L_N), fr.l3(PT_L_D), kd, ks, m[6]);
+                }
+            }
+            if (shaded) value = color;
+        }
+        if (mine) fr.set_l3(PT_L_VALUE, value);
+
+        // render.rs:36-43 under the summation contract: the chunk's samples in ascending order, added by the lane of the chunk's
+        // first sample from its neighbours' LDS columns (same wavefront: program order suffices).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            PtItemLane it;
+            uint32_t x2, y2;
+            const bool mine2 = pt_item_lane(a, w, lane, &it, &x2, &y2);
+            if (mine2 && it.first) {
+                PtVec3 sum = fr.l3(PT_L_VALUE);
+                for (uint32_t k = 1; k < it.count; k++) {
+                    const double* o = fr.lds + k;
+                    sum = sum + pt_v3(o[(PT_L_VALUE + 0) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 1) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 2) * PT_FRAME_STRIDE]);
+                }
+                double* o = a.accum + 3 * ((size_t)(it.slot >> 6) * a.n_chunks * 64 + (size_t)it.chunk * 64 + (it.slot & 63u));
+                o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (STATS) pt_flush_counters(a.counters, cnt);
+}

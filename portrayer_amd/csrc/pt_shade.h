@@ -33,6 +33,9 @@
 //    the chunk's samples in ascending order (the summation contract) and writes the chunk sum.
 #pragma once
 
+#include <stdlib.h>
+
+#include "pt_pow.h"
 #include "pt_trace.h"
 
 #define PT_MAX_DEPTH 10  // material.rs:12
@@ -67,6 +70,16 @@ enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHAD
 enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_HAVE_REFRACT = 4 };  // parked frames
 #define PT_FS_TEXEL 0x80000000u  // hit frame: bits 0..23 are the texel's R, G, B bytes; the diffuse colour is srgb_lut[] of them (texture.rs:162-168)
 #define PT_LIGHT_ROUND 32  // shadow-ray results are kept as one bit per light, 32 lights at a time
+
+// true when PORTRAYER_INTERP=1 asks for the interpreter kernel where the straight-line kernel would run (builds with -DPT_KEEP_INTERP only)
+inline bool pt_interpreter_forced() {
+#ifdef PT_KEEP_INTERP
+    const char* e = getenv("PORTRAYER_INTERP");
+    return e && atoi(e) > 0;
+#else
+    return false;
+#endif
+}
 
 struct PtRenderArgs {
     PtSceneView scene;
@@ -253,13 +266,18 @@ PT_HD PtRay pt_camera_ray(const PtCamera& c, double x, double y) {  // camera.rs
     return r;
 }
 
-// pow is the only libm call on the path (gamma render.rs:47, specular material.rs:200). Kept out of
-// line: the device library's f64 pow needs more registers than the rest of the interpreter, and one
-// shared copy lets the allocator size everything else for a higher occupancy.
-#ifdef PT_POW_INLINE
-PT_HD double pt_pow(double x, double y) { return pow(x, y); }
+// pow is the only libm call on the path (gamma render.rs:47, specular material.rs:200): glibc's pow, restated operation by
+// operation (pt_pow.h), so that linear colours carry the reference's bits. -DPT_POW_OCML keeps the device library's pow (within
+// 1 ulp of glibc's). Out of line: one shared copy lets the register allocator size everything else for a higher occupancy.
+#ifdef PT_POW_OCML
+#define PT_POW_IMPL(x, y) pow(x, y)
 #else
-PT_NOINLINE double pt_pow(double x, double y) { return pow(x, y); }
+#define PT_POW_IMPL(x, y) pt_pow_glibc(x, y)
+#endif
+#ifdef PT_POW_INLINE
+PT_HD double pt_pow(double x, double y) { return PT_POW_IMPL(x, y); }
+#else
+PT_NOINLINE double pt_pow(double x, double y) { return PT_POW_IMPL(x, y); }
 #endif
 
 PT_HD uint8_t pt_to_u8(double c) {  // render.rs:143-147: `as u8` saturates, NaN -> 0
@@ -440,6 +458,72 @@ PT_MAPS_ATTR PtMapsOut pt_apply_maps(const PtTexView* view, uint32_t mat, uint32
     return out;
 }
 
+// flat_scene.rs:85-95 / scene.rs:100-112 + material.rs:109-144 for the winning candidate of a ray: the model-space hit is rebuilt
+// with the reference's expressions, point and normal go to world space (HIER: level by level), the material's maps are applied.
+// Out: world-space point P, shading normal N (normalised geometric normal, or the normal map's), material index, texel tag.
+template <bool TEX, bool HIER>
+PT_HD void pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& hit, PtVec3* P_out, PtVec3* N_out, uint32_t* mat_out, uint32_t* ftag_out) {
+    const uint32_t* info = sc.info + 4 * (size_t)hit.node;
+    uint32_t type = info[0], flags = info[2], mat = info[3];
+    PtRay local = pt_node_local_ray<HIER>(sc, hit.node, ray);
+    PtVec3 p, n;
+    if (type == PT_TRIANGLE || type == PT_MESH || type == PT_KDMESH) {
+        const double* v = sc.tri_v + 9 * (size_t)hit.sub;
+        p = pt_ray_at(local, hit.t);
+        bool smooth = (flags & 1u) != 0;
+        if (smooth) {  // triangle.rs:82-86: re-derive beta / gamma with the same arithmetic
+            double t2, beta, gamma;
+            pt_triangle_hit(v, local, -INFINITY, INFINITY, &t2, &beta, &gamma);
+            double alpha = 1.0 - beta - gamma;
+            const double* vn = sc.tri_n + 9 * (size_t)hit.sub;
+            n = (pt_v3(vn[0], vn[1], vn[2]) * alpha + pt_v3(vn[3], vn[4], vn[5]) * beta) + pt_v3(vn[6], vn[7], vn[8]) * gamma;
+        } else {       // triangle.rs:87: (b - a) x (c - a)
+            PtVec3 A = pt_v3(v[0], v[1], v[2]), B = pt_v3(v[3], v[4], v[5]), C = pt_v3(v[6], v[7], v[8]);
+            n = pt_cross(B - A, C - A);
+        }
+    } else {
+        pt_prim_surface(type, hit.sub, local, hit.t, &p, &n);
+    }
+    PT_FENCE;
+    PtVec3 P, Nw;
+    if (HIER) {  // scene.rs:100-101, :111-112: every level on the way up applies its own trans / normal_trans
+        P = p; Nw = n;
+        for (uint32_t k = sc.chain_off[hit.node + 1]; k-- > sc.chain_off[hit.node];) {
+            P = pt_xform_point(sc.g_fwd + 12 * (size_t)sc.chain[k], P);
+            Nw = pt_xform_dir(sc.g_nrm + 9 * (size_t)sc.chain[k], 3, Nw);
+        }
+    } else {
+        P = pt_xform_point(sc.fwd + 12 * (size_t)hit.node, p);
+        Nw = pt_xform_dir(sc.nrm + 9 * (size_t)hit.node, 3, n);
+    }
+    PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
+    uint32_t ftag = 0;
+    if (TEX && sc.mat_maps && (sc.mat_maps[2 * mat] >= 0 || sc.mat_maps[2 * mat + 1] >= 0)) {  // material.rs:109-144
+        PtMapsOut mo = pt_apply_maps(sc.texview, mat, type, hit.sub, local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z,
+                                     p.x, p.y, p.z, n.x, n.y, n.z);
+        if (mo.has_n) N = pt_v3(mo.n[0], mo.n[1], mo.n[2]);
+        ftag = mo.texel;
+    }
+    *P_out = P; *N_out = N; *mat_out = mat; *ftag_out = ftag;
+}
+
+// material.rs:179-210 for one light that is not occluded: (diffuse + specular) / attenuation. lcol = the light's colour,
+// falloff = its three attenuation coefficients (light.rs:31-33), light_dir / light_dist as the shadow ray was set up.
+PT_HD PtVec3 pt_light_term(PtVec3 lcol, PtVec3 falloff, PtVec3 light_dir, double light_dist, PtVec3 N, PtVec3 ray_dir, PtVec3 kd, PtVec3 ks,
+                           double shininess) {
+    double attenuation = falloff.x + falloff.y * light_dist + falloff.z * light_dist * light_dist;  // light.rs:31-33
+    double normal_light = fmax(pt_dot(N, light_dir), 0.0);
+    PtVec3 diffuse = (kd * lcol) * normal_light;
+    PtVec3 specular = pt_v3(0.0, 0.0, 0.0);
+    if (ks.x > PT_EPSILON || ks.y > PT_EPSILON || ks.z > PT_EPSILON) {
+        PtVec3 view = -ray_dir;
+        PtVec3 half = pt_normalized(view + light_dir);
+        double nhs = pt_pow(fmax(pt_dot(N, half), 0.0), 4.0 * shininess);
+        specular = (ks * lcol) * nhs;
+    }
+    return (diffuse + specular) / attenuation;
+}
+
 // Runs the lane's interpreter until it needs a ray traced (L.has_ray) or its sample is finished
 // (L.stage == PT_ST_DONE, colour in the lane's LDS column). `hit` is the result of the ray the lane traced last.
 #ifdef PT_ADVANCE_NOINLINE  // measured slower at every occupancy (profiles/r01/notes.md)
@@ -530,50 +614,11 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             PT_FENCE;
             if (hit.node == PT_NO_HIT) { PT_LANE_XY(a, L, lx, ly); value = pt_background(a, lx, ly); returning = true; continue; }
             if (STATS) cnt->hits++;
-            // flat_scene.rs:85-95: rebuild the model-space hit, bring point and normal to world space
-            const uint32_t* info = sc.info + 4 * (size_t)hit.node;
-            uint32_t type = info[0], flags = info[2], mat = info[3];
-            PtRay local = pt_node_local_ray<HIER>(sc, hit.node, L.ray);
-            PtVec3 p, n;
-            if (type == PT_TRIANGLE || type == PT_MESH || type == PT_KDMESH) {
-                const double* v = sc.tri_v + 9 * (size_t)hit.sub;
-                p = pt_ray_at(local, hit.t);
-                bool smooth = (flags & 1u) != 0;
-                if (smooth) {  // triangle.rs:82-86: re-derive beta / gamma with the same arithmetic
-                    double t2, beta, gamma;
-                    pt_triangle_hit(v, local, -INFINITY, INFINITY, &t2, &beta, &gamma);
-                    double alpha = 1.0 - beta - gamma;
-                    const double* vn = sc.tri_n + 9 * (size_t)hit.sub;
-                    n = (pt_v3(vn[0], vn[1], vn[2]) * alpha + pt_v3(vn[3], vn[4], vn[5]) * beta) + pt_v3(vn[6], vn[7], vn[8]) * gamma;
-                } else {       // triangle.rs:87: (b - a) x (c - a)
-                    PtVec3 A = pt_v3(v[0], v[1], v[2]), B = pt_v3(v[3], v[4], v[5]), C = pt_v3(v[6], v[7], v[8]);
-                    n = pt_cross(B - A, C - A);
-                }
-            } else {
-                pt_prim_surface(type, hit.sub, local, hit.t, &p, &n);
-            }
-            PT_FENCE;
-            PtVec3 P, Nw;
-            if (HIER) {  // scene.rs:100-101, :111-112: every level on the way up applies its own trans / normal_trans
-                P = p; Nw = n;
-                for (uint32_t k = sc.chain_off[hit.node + 1]; k-- > sc.chain_off[hit.node];) {
-                    P = pt_xform_point(sc.g_fwd + 12 * (size_t)sc.chain[k], P);
-                    Nw = pt_xform_dir(sc.g_nrm + 9 * (size_t)sc.chain[k], 3, Nw);
-                }
-            } else {
-                P = pt_xform_point(sc.fwd + 12 * (size_t)hit.node, p);
-            }
+            PtVec3 P, N;
+            uint32_t mat, ftag;
+            pt_hit_surface<TEX, HIER>(sc, L.ray, hit, &P, &N, &mat, &ftag);
             fr.set_l3(PT_L_P, P);
             PT_FENCE;
-            if (!HIER) Nw = pt_xform_dir(sc.nrm + 9 * (size_t)hit.node, 3, n);
-            PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
-            uint32_t ftag = 0;
-            if (TEX && sc.mat_maps && (sc.mat_maps[2 * mat] >= 0 || sc.mat_maps[2 * mat + 1] >= 0)) {  // material.rs:109-144
-                PtMapsOut mo = pt_apply_maps(sc.texview, mat, type, hit.sub, local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z,
-                                             p.x, p.y, p.z, n.x, n.y, n.z);
-                if (mo.has_n) N = pt_v3(mo.n[0], mo.n[1], mo.n[2]);
-                ftag = mo.texel;
-            }
             fr.set_l3(PT_L_N, N);
             fr.set_l3(PT_L_D, L.ray.d);
             fr.l(PT_L_TAG) = PtFrameRef::pack_tag(mat, ftag);
@@ -624,21 +669,10 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 PtVec3 lpos = pt_light_position(a, L, light, draw, &is_area);
                 if (is_area) draw += 2;
                 if ((L.occluded >> (li - round_first)) & 1u) continue;
-                PtVec3 lcol = pt_v3(light[3], light[4], light[5]);
                 PtVec3 hit_to_light = lpos - P;
                 double light_dist = pt_length(hit_to_light);
                 PtVec3 light_dir = hit_to_light / light_dist;
-                double attenuation = light[6] + light[7] * light_dist + light[8] * light_dist * light_dist;  // light.rs:31-33
-                double normal_light = fmax(pt_dot(N, light_dir), 0.0);
-                PtVec3 diffuse = (kd * lcol) * normal_light;
-                PtVec3 specular = pt_v3(0.0, 0.0, 0.0);
-                if (ks.x > PT_EPSILON || ks.y > PT_EPSILON || ks.z > PT_EPSILON) {
-                    PtVec3 view = -ray_dir;
-                    PtVec3 half = pt_normalized(view + light_dir);
-                    double nhs = pt_pow(fmax(pt_dot(N, half), 0.0), 4.0 * m[6]);
-                    specular = (ks * lcol) * nhs;
-                }
-                color = color + (diffuse + specular) / attenuation;
+                color = color + pt_light_term(pt_v3(light[3], light[4], light[5]), pt_v3(light[6], light[7], light[8]), light_dir, light_dist, N, ray_dir, kd, ks, m[6]);
             }
             if (L.light < sc.n_lights) {  // more than 32 lights: park the colour and do the next 32
                 fr.set_h3(L.depth, PT_H_COLOR, color);

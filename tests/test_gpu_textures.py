@@ -47,7 +47,7 @@ def test_normal_mapping_example_matches_oracle(oracle, host, H, mode):
     # sphere texture coordinates go through atan2 / acos (sphere.rs:57-60): a last-bit difference between
     # the device and glibc can move a sample across a texel boundary; everything else must be identical
     assert bad.sum() <= 2, f"{bad.sum()} pixels differ"
-    assert_ulp(linear[~bad], ref.linear[~bad], 8)
+    assert_ulp(linear[~bad], ref.linear[~bad], 0)
 
 
 def test_gpu_normal_mapping_vs_reference_golden(host, H):
@@ -106,7 +106,7 @@ def test_random_textured_scene_matches_oracle(oracle, host, H, seed, mode):
     assert ref.stats["kd_plane_miss"] == 0
     bad = (rgb != ref.rgb).any(axis=2)
     assert bad.sum() <= 2, f"{bad.sum()} pixels differ, first at {np.argwhere(bad)[:3]}"
-    assert_ulp(linear[~bad], ref.linear[~bad], 8)
+    assert_ulp(linear[~bad], ref.linear[~bad], 0)
 
 
 def test_texture_on_primitive_without_uv_is_rejected(host, H):
