@@ -2,21 +2,26 @@
 """Benchmark of the MI355X ray-cast/shade path: Mray/s (primary + shadow + secondary rays) at
 1920x1080, SAMPLES=64 (BASELINE.json `metric`).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload big-scene] [--traversal flat|kd]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload big-scene] [--traversal flat|kd|hier]
 
 A "step" is one full frame of the workload, inputs resident in HBM (scene uploaded once, background
 rows on the device) when the timed region starts. With N > 1 (launched by torch.distributed.run, one
-rank per GPU) the frame's 8x8 tiles are dealt round-robin to the ranks, every rank renders its tiles
-into a compact device buffer, and ONE gather (RCCL over xGMI; `--backend gloo` on CPU tensors for
-tests) brings them to rank 0, which scatters them into the row-major image: fixed total work, so
-`scaling` is "strong". Rank 0 prints one JSON line.
-
-`python bench.py --gpus N` without a launcher starts its own N rank processes (before anything touches the GPU).
+rank process per GPU, or by this script itself) the frame's 8x8 tiles are dealt round-robin to the GPUs, every
+GPU renders its tiles into a compact device buffer, and ONE gather (RCCL over xGMI) brings them to GPU 0,
+which scatters them into the row-major image: fixed total work, so `scaling` is "strong".
+  --via node  (default) the product's own multi-GPU path: rank 0 drives pt_node_* (include/portrayer_hip.h: one context
+              per GPU in one process, ncclCommInitAll + one grouped ncclGather, pt_untile_device); the other rank
+              processes take part in the barriers only. If the node cannot be set up, the run falls back to
+  --via torch the same partition with one process per GPU and torch.distributed's gather (backend nccl = RCCL;
+              `--backend gloo` on CPU tensors for tests) - the cross-check of the node path.
+Rank 0 prints one JSON line.
 
 The line also carries
-  roofline     : HBM-side bytes per launch of the render kernel (committed rocprofv3 PMC profile of this command)
-                 over its launch duration measured live with HIP events, against the copy bandwidth measured
-                 on this box; SURVEY 8(d)'s algorithmic bytes and the f64-VALU ceiling under their own names;
+  roofline     : the kernel is bound by VALU issue, not by HBM or MFMA: `frac` = the time the vector ALUs need
+                 for SURVEY 8(d)'s algorithmic operations of one launch (f64 at 39.3 T lane-ops/s, the f32 box tests at
+                 78.6) over the kernel's launch duration measured live with HIP events; HBM-side bytes per launch
+                 (`traffic`, from the committed rocprofv3 PMC profile of this very kernel instantiation, else null)
+                 beside the bytes the frame needs, so that wasted traffic shows;
   secondary    : big-soup and the mirror scene at the metric's size (N = 1 default run);
   cpu_baseline : the CPU oracle (a C restatement of the reference, kind "port") timed on this box's
                  host cores on a bounded sample of the same workload: median of 3, pixel loop only.
@@ -31,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-VALU_PEAK_TFLOPS = 39.3  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz scalar-per-lane VALU ops/s (the guide's 157.3 TF FP32 vector peak = this x 2 for fma x 2 for packed f32)
+VALU_PEAK_TOPS = 39.3  # 256 CUs x 4 SIMDs x 16 f64 lanes x 2.4 GHz lane-operations/s (MI355X_MICROARCH.md: 78.6 TFLOP/s vector f64 counts an fma as 2; f32 issues at twice this rate)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 WORKLOADS = {
@@ -59,59 +64,80 @@ def algorithmic_bytes(st, n_lights, pixels, traversal):
             + st["hits"] * (168 + 80 + 120 * n_lights) + 27 * pixels)
 
 
-def algorithmic_flops(st, n_lights, traversal):
-    """SURVEY §8(d) "algorithmic flops per test" (f64 mul / add / div / sqrt / pow each = 1; an fma of
-    the f32 box test = 2): ray->model transform 30 + an average analytic primitive 60 per primitive
-    test; triangle 50; mesh box test 30 + 96; tree step 48 (two boxes x (6 fma + 12 min/max)) in this
-    build's tree or 9 per k-d split; per shaded hit 60 (point, normal, normalise) + 43 per light."""
-    node = 9 if traversal == "kd" else 48
-    return (node * st["n_inner"] + 90 * st["n_analytic"] + 50 * st["n_tri"] + 126 * st["n_bbox"]
-            + st["hits"] * (60 + 43 * n_lights))
+def algorithmic_ops(st, n_lights, traversal):
+    """SURVEY §8(d) "algorithmic flops per test" as VALU issue slots (one lane-operation each: f64 mul / add / div / sqrt /
+    pow = 1; an f32 fma of the box test = 1 slot, 2 flops). Returns (f64 slots, f32 slots, flops).
+    f64: ray -> model transform 30 + an average analytic primitive 60 per primitive test; triangle 50; mesh box test 30 + 96;
+    9 per k-d split; per shaded hit 60 (point, normal, normalise) + 43 per light.
+    f32: a step of this build's tree = two boxes x (6 fma + 12 min / max)."""
+    f64 = (90 * st["n_analytic"] + 50 * st["n_tri"] + 126 * st["n_bbox"] + st["hits"] * (60 + 43 * n_lights)
+           + (9 * st["n_inner"] if traversal == "kd" else 0))
+    f32 = 0 if traversal == "kd" else 36 * st["n_inner"]
+    flops = f64 + (0 if traversal == "kd" else 48 * st["n_inner"])
+    return f64, f32, flops
 
 
-def measured_profile(workload, traversal, n_gpus):
-    """The committed rocprofv3 PMC summary of this workload (profiles/traffic.json, written by profiles/summarise.py
-    from separate --pmc passes over this very command): HBM-side bytes per render-kernel launch (FETCH_SIZE x 2 on
-    gfx950 + WRITE_SIZE, KB -> bytes), lanes active per VALU instruction, VALU busy. None when no profile of this
-    exact workload is committed."""
+def kernel_name(st):
+    """The instantiation pt_stats says ran (ABI 6: kernel_mode / kernel_variant), spelled like rocprofv3's kernel trace spells it."""
+    v = st["kernel_variant"]
+    waves, interp, park, tex = v & 15, bool(v & 16), bool(v & 32), bool(v & 128)
+    t = "true" if tex else "false"
+    if interp:
+        return f"void pt_render_kernel<{st['kernel_mode']}, false, {t}, {1 if park else (2 if waves == 4 else 0)}>(PtRenderArgs)"
+    return f"void pt_render_simple_kernel<{st['kernel_mode']}, false, {t}, {waves}>(PtRenderArgs)"
+
+
+def measured_profile(key, kernel):
+    """The committed rocprofv3 PMC summary of a workload (profiles/traffic.json, written by profiles/summarise.py from separate
+    --pmc passes over this very command): HBM-side bytes per render-kernel launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
+    KB -> bytes), lanes active per VALU instruction, VALU busy. None unless a profile of this exact workload AND of the kernel
+    instantiation that is running now is committed - a profile of another kernel says nothing about this one."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             t = json.load(fh)
-        key = f"{workload}/{traversal}/gpus{n_gpus}"
-        entry = t.get(key)
-        # the kernel variant is part of what was profiled (profiles/r02/notes.md section 16): instantiation "..., 2>" = 4 waves per SIMD
-        four = entry is not None and ", 2>" in entry.get("kernel", "")
-        waves = os.environ.get("PORTRAYER_WAVES")
-        if waves == "3":
-            return t.get(key + "/waves3") if four else entry
-        if waves == "4":
-            return entry if four else None
-        return entry
     except (OSError, ValueError):
         return None
+    for k in (key, key + "/waves3", key + "/waves4"):
+        e = t.get(k)
+        if e is not None and e.get("kernel") == kernel:
+            return e
+    return None
 
 
-def roofline_block(workload, traversal, world, at_config_size, algorithmic, kernel_s, copy_gbps, counts, total, rays_frame, n_lights):
-    """`achieved` / `frac`: HBM-side bytes per launch of the render kernel as the rocprofv3 PMC passes committed under
-    profiles/ measured them for this workload (FETCH_SIZE x 2 + WRITE_SIZE, per the MI355X guide's gfx950 correction)
-    over the kernel's launch duration measured live (HIP events on the launch stream), against `peak` = the copy
-    bandwidth measured on THIS box just now; the 8 TB/s datasheet figure is `spec_peak`. SURVEY 8(d)'s ALGORITHMIC
-    bytes are served by L1 / L2 on every reference scene (0.3 MB scenes), so that figure is reported under its own
-    name and never as a fraction of the HBM roofline. What bounds the kernel is the f64 VALU: `valu`."""
-    prof = measured_profile(workload, traversal, world) if at_config_size else None
+def needed_hbm_bytes(scene_export, pixels, n_chunks):
+    """What one frame has to move through HBM if nothing is read twice: the scene once (node records, triangles, trees), one
+    background colour per pixel, one 24-byte chunk sum per (pixel, 8-sample chunk), written by the render kernel and read by
+    the finishing pass, 3 bytes per pixel out."""
+    n = int(len(scene_export["prim_type"]))
+    tris = int(scene_export["mesh_tri_off"][-1]) + int(scene_export["n_triangles"])
+    scene = n * ((12 + 12 + 9) * 8 + 16) + tris * 72 + (2 * n + tris) * 64
+    return scene + pixels * (24 + 3) + 2 * 24 * pixels * n_chunks
+
+
+def roofline_block(key, at_config_size, st, algorithmic, kernel_s, copy_gbps, counts, total, rays_frame, n_lights, traversal, needed_bytes):
+    """The ceiling of this kernel is VALU issue (`bound`): every scene of the reference fits L2, a tree node is fetched once per
+    wavefront through the scalar cache, and there is no contraction for the matrix cores. `achieved` = SURVEY 8(d)'s algorithmic
+    lane-operations of one launch per second, in f64-rate units (an f32 box-test instruction takes half the issue time of an
+    f64 one on gfx950, so it counts 1/2); `peak` = 39.3 T/s (256 CUs x 4 SIMDs x 16 f64 lanes x 2.4 GHz; parity forbids fma,
+    so one operation per slot); `frac` = achieved / peak = the time the vector ALUs need for the algorithmic work over the
+    launch duration measured live (HIP events on the launch stream). `traffic` = HBM-side bytes per launch from the committed
+    PMC profile of THIS kernel instantiation (null when none is committed); `hbm` sets it against what the frame needs."""
+    name = kernel_name(st)
+    prof = measured_profile(key, name) if at_config_size else None
     traffic = prof.get("hbm_bytes_per_launch") if prof else None
-    achieved = traffic / kernel_s / 1e9 if traffic else None
-    flops = algorithmic_flops(counts, n_lights, traversal)
-    return {"bound": "hbm", "achieved": achieved, "peak": copy_gbps, "unit": "GB/s", "frac": (achieved / copy_gbps) if achieved else None,
-            "traffic": traffic, "spec_peak": HBM_PEAK_GBPS,
-            "basis": ("HBM-side bytes per launch from %s" % prof.get("source", "profiles/traffic.json")) if traffic else "no PMC profile of this exact workload is committed: achieved / frac are null",
-            "kernel": "pt_render_kernel", "kernel_ms": kernel_s * 1e3,
+    f64, f32, flops = algorithmic_ops(counts, n_lights, traversal)
+    achieved = (f64 + 0.5 * f32) / kernel_s / 1e12
+    return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s (f64-rate issue slots)", "frac": achieved / VALU_PEAK_TOPS,
+            "traffic": traffic, "kernel": name, "kernel_ms": kernel_s * 1e3,
+            "valu": {"f64_ops_per_launch": f64, "f32_ops_per_launch": f32, "flops_per_launch_fma_as_2": flops, "TFLOP_per_s_fma_as_2": flops / kernel_s / 1e12,
+                     "issued": ({"lanes_active_of_64": prof.get("lanes_active"), "valu_busy": prof.get("valu_busy"),
+                                 "thread_cycles_valu_over_peak": prof.get("valu_issue_frac")} if prof else None)},
+            "hbm": {"needed_bytes": needed_bytes, "measured_bytes": traffic, "waste_ratio": (traffic / needed_bytes) if traffic else None,
+                    "GBps": (traffic / kernel_s / 1e9) if traffic else None, "measured_copy_GBps": copy_gbps, "spec_GBps": HBM_PEAK_GBPS,
+                    "frac_of_measured_copy": (traffic / kernel_s / 1e9 / copy_gbps) if traffic else None,
+                    "profile": prof.get("source") if prof else "no PMC profile of this kernel instantiation on this workload is committed"},
             "algorithmic": {"bytes_per_launch": algorithmic, "GBps": algorithmic / kernel_s / 1e9,
-                            "over_measured_copy_bandwidth": algorithmic / kernel_s / 1e9 / copy_gbps,
-                            "note": "SURVEY 8(d) per-ray operand bytes x the kernel's own counters; cache-served, NOT HBM traffic (a ratio above 1 is what that means)"},
-            # MI355X vector f64 = 78.6 TFLOP/s counting an fma as 2; parity forbids contraction, so 39.3 T mul-or-add/s
-            "valu": {"achieved": flops / kernel_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / kernel_s / 1e12 / VALU_PEAK_TFLOPS,
-                     "lanes_active_of_64": prof.get("lanes_active") if prof else None, "valu_busy": prof.get("valu_busy") if prof else None},
+                            "note": "SURVEY 8(d) per-ray operand bytes x the kernel's own counters; served by the scalar cache / L2, NOT HBM traffic"},
             "per_ray": {"inner_nodes": total["n_inner"] / rays_frame, "primitive_tests": total["n_analytic"] / rays_frame,
                         "triangle_tests": total["n_tri"] / rays_frame}}
 
@@ -124,29 +150,36 @@ def timed_frame(host, H, scene, traverse, device, w, h, s, bg, repeats=3):
     _, _, c = r.render(scene.camera, w, h, bg, samples=s, seed=0, sample_mode=H.SAMPLE_RNG, into=img, want_linear=False, stats=True)
     rays = c["primary"] + c["shadow"] + c["reflect"] + c["refract"]
     best = None
+    st = None
     for _ in range(repeats):
         _, _, st = r.render(scene.camera, w, h, bg, samples=s, seed=0, sample_mode=H.SAMPLE_RNG, into=img, want_linear=False)
         best = st["kernel_ms"] if best is None else min(best, st["kernel_ms"])
     prep = r.prepare_ms()
     r.close()
-    return {"kernel_ms_per_frame": best, "rays_per_frame": rays, "Mray_per_s": rays / best / 1e3, "counters": c, "prepare_ms": prep}
+    return {"kernel_ms_per_frame": best, "rays_per_frame": rays, "Mray_per_s": rays / best / 1e3, "kernel": kernel_name(st), "counters": c, "prepare_ms": prep}
+
+
+def row_background(h):
+    """the example scripts' background closure (one colour per row), e.g. examples/big-scene.rs:94"""
+    import numpy as np
+    v = np.arange(h, dtype=np.float64) / float(h)
+    return np.ascontiguousarray(np.array([0.2, 0.4, 0.6])[None, :] * (1.0 - v)[:, None] + np.array([0.0, 0.0, 1.0])[None, :] * v[:, None])
 
 
 def secondary_workload(host, H, lib, name, device, copy_gbps):
     """big-soup (1.25 M baked triangles: the one input beyond the caches) and the mirror scene (reflection recursion) at the
     metric's size, 1920x1080 SAMPLES=64, flat_scene semantics, kernel time from HIP events."""
-    import numpy as np
     example, n, _, _, _ = WORKLOADS[name]
     w, h, s = 1920, 1080, 64
     scene = host.Scene.example(example, n=n or 10)
-    v = np.arange(h, dtype=np.float64) / float(h)
-    bg = np.ascontiguousarray(np.array([0.2, 0.4, 0.6])[None, :] * (1.0 - v)[:, None] + np.array([0.0, 0.0, 1.0])[None, :] * v[:, None])
-    t = timed_frame(host, H, scene, H.TRAVERSE_FLAT, device, w, h, s, bg, repeats=2)
+    t = timed_frame(host, H, scene, H.TRAVERSE_FLAT, device, w, h, s, row_background(h), repeats=2)
     c = t.pop("counters")
-    prof = measured_profile(name + "@1920x1080x64", "flat", 1)
+    prof = measured_profile(name + "@1920x1080x64/flat/gpus1", t["kernel"])
     traffic = prof.get("hbm_bytes_per_launch") if prof else None
     gbps = traffic / (t["kernel_ms_per_frame"] * 1e-3) / 1e9 if traffic else None
-    return dict(t, workload=f"{example} 1920x1080 SAMPLES=64, flat", traffic=traffic, hbm_GBps=gbps, frac_of_measured_copy_bandwidth=(gbps / copy_gbps) if gbps else None,
+    f64, f32, _ = algorithmic_ops(c, scene.export()["n_lights"], "flat")
+    return dict(t, workload=f"{example} 1920x1080 SAMPLES=64, flat", valu_frac=(f64 + 0.5 * f32) / (t["kernel_ms_per_frame"] * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                traffic=traffic, hbm_GBps=gbps, frac_of_measured_copy_bandwidth=(gbps / copy_gbps) if gbps else None,
                 lanes_active_of_64=prof.get("lanes_active") if prof else None,
                 per_ray={"inner_nodes": c["n_inner"] / t["rays_per_frame"], "triangle_tests": c["n_tri"] / t["rays_per_frame"]})
 
@@ -187,12 +220,13 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--samples", type=int, default=0)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
-    ap.add_argument("--same-device", action="store_true", help="testing: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--via", default="node", choices=["node", "torch"], help="N > 1: the product's pt_node_* on rank 0 (default), or torch.distributed's gather with one process per GPU")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="--via torch: the collective's backend")
+    ap.add_argument("--same-device", action="store_true", help="testing on a 1-GPU box: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="profiling: only the headline kernel (no host-buffer pass, no default-semantics pass)")
     ap.add_argument("--check", action="store_true", help="compare rank 0's assembled image with a single-GPU render")
-    ap.add_argument("--no-pipeline", action="store_true", help="nccl path: wait for each frame's gather before rendering the next")
+    ap.add_argument("--no-pipeline", action="store_true", help="--via torch, nccl: wait for each frame's gather before rendering the next")
     ap.add_argument("--force-dist", action="store_true", help="testing: take the torch.distributed path even with one rank")
     ap.add_argument("--share", type=int, default=1, help="testing: render only one rank's tiles of an N-rank partition (no gather)")
     ap.add_argument("--share-rank", type=int, default=0, help="testing: which rank's tiles --share renders")
@@ -209,14 +243,17 @@ def main():
     args.gpus = world
     dist = torch = None
     use_dist = world > 1 or args.force_dist
+    via_node = world > 1 and args.via == "node"
+    # the process group: with --via node it only carries the barriers and the fall-back decision (gloo: the rank processes other than 0
+    # never touch a GPU, rank 0's GPUs belong to pt_node alone); with --via torch it carries the frame's gather (nccl = RCCL)
+    pg_backend = "gloo" if via_node else args.backend
     if use_dist:
-        # torch first: its bundled HIP runtime and ours share a SONAME; loaded in this order the
-        # process ends up with ONE runtime.
+        # torch first: its bundled HIP runtime and ours share a SONAME; loaded in this order the process ends up with ONE runtime.
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=pg_backend, rank=rank, world_size=world)
 
     import ctypes as C
 
@@ -227,24 +264,93 @@ def main():
 
     example, n, w, h, s = WORKLOADS[args.workload]
     w, h, s = args.width or w, args.height or h, args.samples or s
+    lib = H.lib()
+    bg = row_background(h)
+    traverse = {"kd": H.TRAVERSE_KD, "hier": H.TRAVERSE_HIER}.get(args.traversal, H.TRAVERSE_FLAT)
+    keys = ["primary", "shadow", "reflect", "refract", "hits", "n_inner", "n_leaf", "n_analytic", "n_tri", "n_bbox"]
+
+    # ---------------------------------------------------------------- the product's multi-GPU path: rank 0 drives pt_node_*
+    node_note = None
+    if via_node:
+        state = {}
+        if rank == 0:
+            try:
+                devices = [0] * world if args.same_device else list(range(world))
+                os.environ["PORTRAYER_DEVICES"] = ",".join(map(str, devices))  # the C++ Renderer puts the scene on a pt_node of these GPUs
+                t0 = time.perf_counter()
+                scene = host.Scene.example(example, n=n or 10)
+                t1 = time.perf_counter()
+                renderer = host.Renderer(scene, traverse, kd_depth=10, device=devices[0])
+                t2 = time.perf_counter()
+                node = renderer.node
+                if not node or lib.pt_node_ranks(node) != world:
+                    raise RuntimeError("the renderer did not come up on a pt_node of %d ranks" % world)
+                cam = host.camera(scene.camera, w, h)
+                pp = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, 0, 1, 0)
+                if lib.pt_node_upload_background(node, bg.ctypes.data_as(H._dp), C.byref(pp), None) != 0:
+                    raise RuntimeError("pt_node_upload_background: " + lib.pt_node_last_error(node).decode())
+
+                def node_step(stats=False):
+                    q = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, 0, 1, 1 if stats else 0)
+                    st = H.PtStats()
+                    if lib.pt_node_render_resident(node, C.byref(cam), C.byref(q), C.byref(st)) != 0:
+                        raise RuntimeError("pt_node_render_resident: " + lib.pt_node_last_error(node).decode())
+                    return st.as_dict()
+                counts = node_step(stats=True)  # also the proof that the whole path runs before anything is timed
+                state = dict(scene=scene, renderer=renderer, node=node, cam=cam, step=node_step, counts=counts, prep=(t0, t1, t2), devices=devices)
+            except Exception as e:  # noqa: BLE001 - whatever went wrong, the run falls back to the torch path and says so
+                node_note = f"{type(e).__name__}: {e}"
+                os.environ.pop("PORTRAYER_DEVICES", None)
+        flag = [node_note]
+        dist.broadcast_object_list(flag, src=0)
+        node_note = flag[0]
+        if node_note is None:
+            out = None
+            for _ in range(args.warmup):
+                if rank == 0:
+                    state["step"]()
+            dist.barrier()
+            t0 = time.perf_counter()
+            kernel_ms = []
+            if rank == 0:
+                for _ in range(args.steps):
+                    kernel_ms.append(state["step"]()["kernel_ms"])  # returns when the frame is assembled on GPU 0 (every rank's stream synchronised)
+            dist.barrier()
+            elapsed = time.perf_counter() - t0
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            if rank == 0:
+                out = node_report(args, H, host, lib, state, world, w, h, s, example, elapsed, kernel_ms, bg)
+            dist.barrier()
+            dist.destroy_process_group()
+            if out is not None:
+                sys.stderr.flush()
+                C.CDLL(None).fflush(None)  # RCCL's banner goes through C stdio: flush it before the JSON line
+                print(json.dumps(out), flush=True)
+            return
+        # fall back: a fresh process group for the collective itself (the gloo one carried the decision)
+        dist.destroy_process_group()
+        os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + 1)
+        pg_backend = args.backend
+        dist.init_process_group(backend=pg_backend, rank=rank, world_size=world)
+
+    # ---------------------------------------------------------------- one GPU, or one process per GPU with torch.distributed's gather
     device = 0 if args.same_device else local_rank
     t_prep0 = time.perf_counter()
     scene = host.Scene.example(example, n=n or 10)  # the product's C++ scene scripts (examples/*.cpp), synthetic variants included
-    traverse = {"kd": H.TRAVERSE_KD, "hier": H.TRAVERSE_HIER}.get(args.traversal, H.TRAVERSE_FLAT)
     t_prep1 = time.perf_counter()
     renderer = host.Renderer(scene, traverse, kd_depth=10, device=device)  # flatten + build + upload: once, outside the timed region
     t_prep2 = time.perf_counter()
     ctx = renderer.context
-    lib = H.lib()
     cam = host.camera(scene.camera, w, h)
-    n_lights = scene.export()["n_lights"]
+    export = scene.export()
+    n_lights = export["n_lights"]
 
     def check(rc, what):
         if rc != 0:
             raise RuntimeError(f"{what} failed with {rc}: {lib.pt_last_error(ctx).decode()}")
 
-    v = np.arange(h, dtype=np.float64) / float(h)  # the example scripts' background closure, one colour per row
-    bg = np.ascontiguousarray(np.array([0.2, 0.4, 0.6])[None, :] * (1.0 - v)[:, None] + np.array([0.0, 0.0, 1.0])[None, :] * v[:, None])
     d_bg = C.c_void_p()
     check(lib.pt_device_alloc(ctx, bg.nbytes, C.byref(d_bg)), "pt_device_alloc")
     check(lib.pt_copy_to_device(ctx, d_bg, bg.ctypes.data_as(C.c_void_p), bg.nbytes), "pt_copy_to_device")
@@ -255,8 +361,8 @@ def main():
     p = params(False)
     compact_bytes = int(lib.pt_compact_bytes(C.byref(p)))
     if use_dist:
-        dev = torch.device("cpu") if args.backend == "gloo" else torch.device(f"cuda:{device}")
-        if args.backend == "nccl":
+        dev = torch.device("cpu") if pg_backend == "gloo" else torch.device(f"cuda:{device}")
+        if pg_backend == "nccl":
             torch.cuda.set_device(device)
         # two sets of buffers: frame k+1 is rendered while frame k's tiles travel (nccl path)
         mine_ts = [torch.empty(compact_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -265,21 +371,21 @@ def main():
         mine_t, gathered_t, gather_list = mine_ts[0], gathered_ts[0], gather_lists[0]
     # renders go to a stream of their own on the RCCL path, so that waiting for torch's current stream (the gather's
     # hand-over) never waits for the render of the next frame
-    render_stream = torch.cuda.Stream(device=dev) if (use_dist and args.backend == "nccl") else None
+    render_stream = torch.cuda.Stream(device=dev) if (use_dist and pg_backend == "nccl") else None
     hip_stream = C.c_void_p(render_stream.cuda_stream) if render_stream is not None else None
     d_mine = C.c_void_p()
-    if use_dist and args.backend == "gloo":
+    if use_dist and pg_backend == "gloo":
         check(lib.pt_device_alloc(ctx, compact_bytes, C.byref(d_mine)), "pt_device_alloc")
     d_full = C.c_void_p(); d_gath = C.c_void_p()
     if rank == 0:
         check(lib.pt_device_alloc(ctx, w * h * 3, C.byref(d_full)), "pt_device_alloc")
-        if use_dist and args.backend == "gloo":
+        if use_dist and pg_backend == "gloo":
             check(lib.pt_device_alloc(ctx, compact_bytes * world, C.byref(d_gath)), "pt_device_alloc")
 
     def sync_all():
         if use_dist:
             dist.barrier()
-            if args.backend == "nccl":
+            if pg_backend == "nccl":
                 torch.cuda.synchronize()
 
     def step(stats=False):
@@ -288,18 +394,18 @@ def main():
         st = H.PtStats()
         if not use_dist:
             target, compact = d_full, 0
-        elif args.backend == "nccl":
+        elif pg_backend == "nccl":
             target, compact = C.c_void_p(mine_t.data_ptr()), 1  # render straight into the tensor RCCL sends from
         else:
             target, compact = d_mine, 1
         check(lib.pt_render_device(ctx, C.byref(cam), d_bg, C.byref(pp), compact, target, hip_stream), "pt_render_device")
         check(lib.pt_render_finish(ctx, C.byref(st)), "pt_render_finish")  # waits for the kernel (HIP event)
         if use_dist:
-            if args.backend == "gloo":
+            if pg_backend == "gloo":
                 check(lib.pt_copy_from_device(ctx, C.c_void_p(mine_t.data_ptr()), d_mine, compact_bytes), "pt_copy_from_device")
             dist.gather(mine_t, gather_list, dst=0)  # the single collective of the frame
             if rank == 0:
-                if args.backend == "nccl":
+                if pg_backend == "nccl":
                     torch.cuda.synchronize()
                     src = C.c_void_p(gathered_t.data_ptr())
                 else:
@@ -340,7 +446,6 @@ def main():
     counts = step(stats=True)
     if counts["stack_overflow"]:
         raise RuntimeError("traversal stack overflow")
-    keys = ["primary", "shadow", "reflect", "refract", "hits", "n_inner", "n_leaf", "n_analytic", "n_tri", "n_bbox"]
     total = dict(counts)
     if use_dist:
         t = torch.tensor([counts[k] for k in keys], dtype=torch.int64, device=mine_t.device)
@@ -351,14 +456,16 @@ def main():
     if os.environ.get("PT_DUMP_COUNTERS") and rank == 0:  # kernel experiments (profiles/ab.sh builds with -DPT_PHASE_TIMING)
         print("counters", json.dumps({k: int(v) if isinstance(v, (int, np.integer)) else v for k, v in counts.items()}), file=sys.stderr)
 
-    pipelined = use_dist and args.backend == "nccl" and not args.no_pipeline
+    pipelined = use_dist and pg_backend == "nccl" and not args.no_pipeline
     for _ in range(args.warmup):
         step()
     sync_all()
     t0 = time.perf_counter()
     kernel_ms = []
+    last = None
     for k in range(args.steps):
-        kernel_ms.append((step_pipelined(k) if pipelined else step())["kernel_ms"])
+        last = step_pipelined(k) if pipelined else step()
+        kernel_ms.append(last["kernel_ms"])
     if pipelined:
         drain()  # every frame assembled on rank 0 before the clock stops
     sync_all()
@@ -378,33 +485,20 @@ def main():
 
     if rank == 0:
         mean_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-        mine_bytes = algorithmic_bytes(counts, n_lights, compact_bytes // 3 if use_dist else w * h, args.traversal)
+        own_pixels = compact_bytes // 3 if use_dist else w * h
+        mine_bytes = algorithmic_bytes(counts, n_lights, own_pixels, args.traversal)
         at_config_size = (w, h, s) == WORKLOADS[args.workload][2:] and args.share == 1
         copy_gbps = C.c_double(0.0)
-        check(lib.pt_measure_copy_bandwidth(ctx, 1 << 30, 5, C.byref(copy_gbps)), "pt_measure_copy_bandwidth")  # this box's HBM roofline
+        check(lib.pt_measure_copy_bandwidth(ctx, 1 << 30, 5, C.byref(copy_gbps)), "pt_measure_copy_bandwidth")  # this box's copy bandwidth, beside the 8 TB/s of the data sheet
         prep = renderer.prepare_ms()
-        out = {
-            "metric": "Mray/s (primary+shadow+secondary) at 1920x1080 SAMPLES=64" if (w, h, s) == (1920, 1080, 64) else f"Mray/s (primary+shadow+secondary) at {w}x{h} SAMPLES={s}",
-            "value": rays_frame * args.steps / elapsed / 1e6,
-            "unit": "Mray/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{example} (the big-scene generator over cow.obj: 216 instances, 1,253,664 triangles; SURVEY 8d synthetic) {w}x{h} SAMPLES={s}"
-                                    if example.startswith("synthetic:") else
-                                    f"{example} ({'1000 analytic primitives, 3 point lights, ' if example == 'big-scene' else ''}reference scene script) {w}x{h} SAMPLES={s}"),
-                       "width": w, "height": h, "samples": s, "traversal": args.traversal, "sampling": "counter-based jitter, seed 0",
-                       "partition": f"8x8 tiles round-robin over {world} rank(s), one gather" if world > 1 else "single GPU",
-                       "collective": ({"backend": "nccl = RCCL over xGMI" if args.backend == "nccl" else args.backend, "ranks_in_group": dist.get_world_size(),
-                                       "per_frame": "one gather of %d B per rank" % compact_bytes} if use_dist else None),
-                       "rays_per_frame": rays_frame,
-                       # what a drop-in pays before the first pixel (the reference converts the scene inside every render call, render.rs:115-126)
-                       "prepare_ms": dict(prep, scene_script=(t_prep1 - t_prep0) * 1e3, renderer_total=(t_prep2 - t_prep1) * 1e3),
-                       "rays": {k: total[k] for k in ("primary", "shadow", "reflect", "refract")}},
-            "roofline": roofline_block(args.workload, args.traversal, world, at_config_size, mine_bytes, mean_kernel_s, float(copy_gbps.value),
-                                       counts, total, rays_frame, n_lights),
-        }
+        out = headline(args, example, w, h, s, world, rays_frame, elapsed, total)
+        out["config"]["collective"] = ({"via": "torch.distributed gather, one process per GPU" + (f" (fell back from pt_node: {node_note})" if node_note else ""),
+                                        "backend": "nccl = RCCL over xGMI" if pg_backend == "nccl" else pg_backend, "ranks_in_group": dist.get_world_size(),
+                                        "per_frame": "one gather of %d B per rank" % compact_bytes} if use_dist else None)
+        # what a drop-in pays before the first pixel (the reference converts the scene inside every render call, render.rs:115-126)
+        out["config"]["prepare_ms"] = dict(prep, scene_script=(t_prep1 - t_prep0) * 1e3, renderer_total=(t_prep2 - t_prep1) * 1e3)
+        out["roofline"] = roofline_block(f"{args.workload}/{args.traversal}/gpus{world}", at_config_size, last, mine_bytes, mean_kernel_s, float(copy_gbps.value),
+                                         counts, total, rays_frame, n_lights, args.traversal, needed_hbm_bytes(export, own_pixels, (s + 7) // 8))
         if ok is not None:
             out["config"]["assembled_image_equals_single_gpu_render"] = ok
         if world == 1 and not args.no_extras:
@@ -436,6 +530,69 @@ def main():
         # when stdout is a pipe or a file: flush it now so that the JSON is the last line on stdout
         C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)  # the one JSON line, last thing on rank 0's stdout
+
+
+def headline(args, example, w, h, s, world, rays_frame, elapsed, total):
+    """The fields of the JSON line every path shares."""
+    return {
+        "metric": "Mray/s (primary+shadow+secondary) at 1920x1080 SAMPLES=64" if (w, h, s) == (1920, 1080, 64) else f"Mray/s (primary+shadow+secondary) at {w}x{h} SAMPLES={s}",
+        "value": rays_frame * args.steps / elapsed / 1e6,
+        "unit": "Mray/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"{example} (the big-scene generator over cow.obj: 216 instances, 1,253,664 triangles; SURVEY 8d synthetic) {w}x{h} SAMPLES={s}"
+                                if example.startswith("synthetic:") else
+                                f"{example} ({'1000 analytic primitives, 3 point lights, ' if example == 'big-scene' else ''}reference scene script) {w}x{h} SAMPLES={s}"),
+                   "width": w, "height": h, "samples": s, "traversal": args.traversal, "sampling": "counter-based jitter, seed 0",
+                   "partition": f"8x8 tiles round-robin over {world} GPU(s), one gather" if world > 1 else "single GPU",
+                   "rays_per_frame": rays_frame,
+                   "rays": {k: total[k] for k in ("primary", "shadow", "reflect", "refract")}},
+    }
+
+
+def node_report(args, H, host, lib, state, world, w, h, s, example, elapsed, kernel_ms, bg):
+    """Rank 0's JSON line of the --via node path: the frame went through pt_node_render_resident."""
+    import ctypes as C
+
+    import numpy as np
+    counts, node, scene, renderer = state["counts"], state["node"], state["scene"], state["renderer"]
+    if counts["stack_overflow"]:
+        raise RuntimeError("traversal stack overflow")
+    rays_frame = counts["primary"] + counts["shadow"] + counts["reflect"] + counts["refract"]
+    export = scene.export()
+    out = headline(args, example, w, h, s, world, rays_frame, elapsed, counts)
+    ranks = int(lib.pt_node_ranks(node))
+    pp = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, 0, ranks, 0)
+    per = int(lib.pt_compact_bytes(C.byref(pp)))
+    out["config"]["collective"] = {"via": "pt_node_render_resident (include/portrayer_hip.h): one process, one context per GPU",
+                                   "backend": "RCCL: ncclCommInitAll + one grouped ncclGather over xGMI" if lib.pt_node_uses_rccl(node) else "device-to-device copies (ranks share a GPU: RCCL needs distinct devices)",
+                                   "uses_rccl": bool(lib.pt_node_uses_rccl(node)), "ranks_in_group": ranks,
+                                   "devices": [int(lib.pt_node_device(node, r)) for r in range(ranks)],
+                                   "per_frame": "one gather of %d B per rank" % per, "rank_processes": world}
+    t0, t1, t2 = state["prep"]
+    out["config"]["prepare_ms"] = dict(renderer.prepare_ms(), scene_script=(t1 - t0) * 1e3, renderer_total=(t2 - t1) * 1e3)
+    if args.check:
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        if lib.pt_node_download_image(node, C.byref(pp), img.ctypes.data_as(H._u8p)) != 0:
+            raise RuntimeError("pt_node_download_image: " + lib.pt_node_last_error(node).decode())
+        os.environ.pop("PORTRAYER_DEVICES", None)
+        one = host.Renderer(scene, {"kd": H.TRAVERSE_KD, "hier": H.TRAVERSE_HIER}.get(args.traversal, H.TRAVERSE_FLAT), kd_depth=10, device=state["devices"][0])
+        ref = np.zeros((h, w, 3), dtype=np.uint8)
+        one.render(scene.camera, w, h, bg, samples=s, seed=0, sample_mode=H.SAMPLE_RNG, into=ref, want_linear=False)
+        one.close()
+        out["config"]["assembled_image_equals_single_gpu_render"] = bool(np.array_equal(img, ref))
+    # the roofline of the slowest rank's kernel: the counters are the node's totals, a rank's share is 1 / ranks of them
+    share = {k: v / ranks if isinstance(v, (int, float)) and k not in ("kernel_ms", "total_ms", "kernel_mode", "kernel_variant") else v for k, v in counts.items()}
+    mean_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+    copy_gbps = C.c_double(0.0)
+    lib.pt_measure_copy_bandwidth(lib.pt_node_context(node, 0), 1 << 30, 5, C.byref(copy_gbps))
+    n_lights = export["n_lights"]
+    out["roofline"] = roofline_block(f"{args.workload}/{args.traversal}/gpus{world}", False, counts, algorithmic_bytes(share, n_lights, w * h // ranks, args.traversal), mean_kernel_s,
+                                     float(copy_gbps.value), share, counts, rays_frame, n_lights, args.traversal, needed_hbm_bytes(export, w * h // ranks, (s + 7) // 8))
+    out["roofline"]["note"] = "per GPU: the slowest rank's kernel time against 1 / ranks of the frame's counters"
+    return out
 
 
 def cpu_baseline(example, n, w, h, traversal):

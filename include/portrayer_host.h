@@ -99,6 +99,8 @@ void ph_renderer_destroy(ph_renderer *r);
 pt_context *ph_renderer_context(ph_renderer *r);
 /* 1, or the number of ranks when PORTRAYER_GPUS / PORTRAYER_DEVICES put the scene on a node (pt_node_*) */
 int ph_renderer_ranks(ph_renderer *r);
+/* the pt_node behind the renderer in that case (NULL on a single GPU): for callers that drive pt_node_render_resident themselves */
+pt_node *ph_renderer_node(ph_renderer *r);
 /* where the time before the first pixel went, in ms: flatten (flat_scene.rs:18-46), packing the ABI arrays, context / node
  * creation, the reference's k-d tree build (kdtree feature only), pt_scene_upload (device trees included) */
 int ph_renderer_prepare_ms(ph_renderer *r, double out[5]);

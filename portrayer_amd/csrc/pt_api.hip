@@ -805,17 +805,17 @@ static int pt_check_params(pt_context* c, const pt_camera* cam, const pt_render_
     return PT_OK;
 }
 
-// a.park_slots / a.four_waves select the instantiation: 1 with a parked recursion frame in LDS, 2 for 4 waves per SIMD, 0 neither.
+// a.run_variant (PT_RUN_*, pt_render_kernel.h) selects the kernel.
 static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
     const bool tex = a.scene.mat_maps != nullptr;
     switch (a.scene.mode) {
-    case PT_MODE_KD: return pt_launch_mode_2(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_FLAT_NOMESH: return pt_launch_mode_3(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_FLAT_KDMESH: return pt_launch_mode_4(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_HIER: return pt_launch_mode_5(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
-    case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
-    default: return pt_launch_mode_1(a, a.park_slots ? 1 : (a.four_waves ? 2 : 0), stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_KD: return pt_launch_mode_2(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_FLAT_NOMESH: return pt_launch_mode_3(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_FLAT_KDMESH: return pt_launch_mode_4(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER: return pt_launch_mode_5(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
+    default: return pt_launch_mode_1(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     }
 }
 
@@ -896,8 +896,15 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.park_slots = 1;
     if (const char* e = getenv("PORTRAYER_PARK")) a.park_slots = atoi(e) > 0 ? 1 : 0;  // 0: every parked frame in HBM (tests, measurements)
     if (!c->spawns) a.park_slots = 0;
-    a.four_waves = (!a.park_slots && c->four_waves) ? 1 : 0;
-    if (const char* e = getenv("PORTRAYER_WAVES")) a.four_waves = (!a.park_slots && atoi(e) == 4) ? 1 : 0;
+    // Scenes whose hits spawn rays need the interpreter kernel (3 waves per SIMD); the others run the straight-line kernel at 3 or
+    // 4 waves per SIMD. PORTRAYER_INTERP=1 (builds with -DPT_KEEP_INTERP): the interpreter on those too, for A/B runs.
+    const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH;
+    a.four_waves = (!c->spawns && c->four_waves) ? 1 : 0;
+    if (const char* e = getenv("PORTRAYER_WAVES")) a.four_waves = (!c->spawns && atoi(e) == 4) ? 1 : 0;
+    if (kd_sem) a.four_waves = 0;
+    if (c->spawns) a.run_variant = a.park_slots ? PT_RUN_INTERP_PARK : PT_RUN_INTERP;
+    else if (pt_interpreter_forced()) a.run_variant = a.four_waves ? PT_RUN_INTERP4 : PT_RUN_INTERP;
+    else a.run_variant = a.four_waves ? PT_RUN_LINE4 : PT_RUN_LINE3;
     size_t block_budget = a.four_waves ? 39 * 1024 : 52 * 1024;  // 3 x 52 KB or 4 x 39 KB of the CU's 160 KB
     if (const char* e = getenv("PORTRAYER_LDS_BUDGET_KB")) block_budget = (size_t)std::max(16, std::min(160, atoi(e))) * 1024;  // experiment: 80 = two blocks per CU
     const size_t frame_bytes = (size_t)(PT_LDS_FRAME_F64 + a.park_slots * PT_PARK_F64) * PT_BLOCK * 8;
@@ -943,9 +950,8 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.counters = (PtCounters*)((char*)c->misc.p + 256);
     a.work_queues = (unsigned int*)((char*)c->misc.p + 256 + sizeof(PtCounters));
     c->last_mode = (uint32_t)a.scene.mode;
-    c->last_variant = (a.four_waves ? 4u : 3u) | (a.park_slots ? (PT_KERNEL_INTERPRETER | PT_KERNEL_PARK) : (pt_interpreter_forced() ? PT_KERNEL_INTERPRETER : 0u)) |
-                      (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
-    if ((a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH) && a.four_waves) c->last_variant = (c->last_variant & ~15u) | 3u;  // no 4-wave k-d instantiation
+    c->last_variant = (a.four_waves ? 4u : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4) ? 0u : PT_KERNEL_INTERPRETER) |
+                      (a.run_variant == PT_RUN_INTERP_PARK ? PT_KERNEL_PARK : 0u) | (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
     if (a.n_items) {

@@ -1,5 +1,5 @@
 // One traversal mode's instantiations of pt_render_kernel (counting / plain, textured / untextured,
-// the three variants of pt_render_kernel.h) and their launcher. Compiled once per mode: -DPT_INST_MODE=1..7 (Makefile).
+// the variants listed in pt_render_kernel.h) and their launcher. Compiled once per mode: -DPT_INST_MODE=1..7 (Makefile).
 #include "pt_render_kernel.h"
 #include "pt_render_inst.h"
 
@@ -11,9 +11,5 @@
 
 hipError_t PT_INST_CAT(pt_launch_mode_, PT_INST_MODE)(const PtRenderArgs& a, int variant, bool stats, bool tex, int n_cu, hipStream_t stream,
                                                       uint32_t* grid, bool launch) {
-    if (variant == 1) return pt_dispatch_variant<PT_INST_MODE, 1>(a, stats, tex, n_cu, stream, grid, launch);
-#if PT_INST_MODE != 2 && PT_INST_MODE != 7  // the k-d tree semantics (per-lane walk) have no 4-wave instantiation: measured slower there
-    if (variant == 2) return pt_dispatch_variant<PT_INST_MODE, 2>(a, stats, tex, n_cu, stream, grid, launch);
-#endif
-    return pt_dispatch_variant<PT_INST_MODE, 0>(a, stats, tex, n_cu, stream, grid, launch);
+    return pt_dispatch_variant<PT_INST_MODE>(a, variant, stats, tex, n_cu, stream, grid, launch);
 }

@@ -261,23 +261,32 @@ static hipError_t pt_launch_kernel(Kernel kernel, size_t lds, const PtRenderArgs
     return hipGetLastError();
 }
 
-// VAR 1 (reflective scenes) is the interpreter kernel; VAR 0 / 2 (hits spawn nothing; 3 / 4 waves per SIMD) the straight-line
-// kernel of pt_render_simple.h. -DPT_KEEP_INTERP also builds the interpreter for VAR 0 / 2 (PORTRAYER_INTERP=1 selects it: A/B runs).
-template <int MODE, bool STATS, bool TEX, int VAR>
-static hipError_t pt_launch(const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
-    const size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, VAR == 1 ? 1 : 0);
-    if constexpr (VAR == 1) {
-        return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, VAR>, lds, a, n_cu, stream, grid_out, launch);
-    } else {
+// Which kernel runs (`variant`, chosen in pt_render_common):
+//   PT_RUN_INTERP / PT_RUN_INTERP_PARK   the interpreter kernel (scenes with reflective materials: hits spawn rays), every parked
+//                                        recursion frame in HBM / the youngest in LDS; 3 waves per SIMD
+//   PT_RUN_LINE3 / PT_RUN_LINE4          the straight-line kernel of pt_render_simple.h (hits spawn nothing), 3 / 4 waves per SIMD
+//   PT_RUN_INTERP4                       -DPT_KEEP_INTERP builds only: the interpreter at 4 waves per SIMD on a scene without reflective
+//                                        materials (what round 2 timed), for A/B runs against the straight-line kernel
+template <int MODE, bool STATS, bool TEX>
+static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_mode, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
+    const size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, variant == PT_RUN_INTERP_PARK ? 1 : 0);
+    switch (variant) {
+    case PT_RUN_INTERP_PARK: return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 1>, lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_INTERP: return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
 #ifdef PT_KEEP_INTERP
-        if (pt_interpreter_forced()) return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, VAR>, lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_INTERP4:
+        if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 2>, lds, a, n_cu, stream, grid_out, launch);
+        return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
 #endif
-        return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, PT_VAR_WAVES(VAR)>, lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_LINE4:  // the k-d tree semantics (per-lane walk) have no 4-wave instantiation: measured slower there
+        if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 4>, lds, a, n_cu, stream, grid_out, launch);
+        [[fallthrough]];
+    default: return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 3>, lds, a, n_cu, stream, grid_out, launch);
     }
 }
 
-template <int MODE, int VAR>
-static hipError_t pt_dispatch_variant(const PtRenderArgs& a, bool stats, bool tex, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
-    if (tex) return stats ? pt_launch<MODE, true, true, VAR>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, true, VAR>(a, n_cu, stream, grid, launch);
-    return stats ? pt_launch<MODE, true, false, VAR>(a, n_cu, stream, grid, launch) : pt_launch<MODE, false, false, VAR>(a, n_cu, stream, grid, launch);
+template <int MODE>
+static hipError_t pt_dispatch_variant(const PtRenderArgs& a, int variant, bool stats, bool tex, int n_cu, hipStream_t stream, uint32_t* grid, bool launch) {
+    if (tex) return stats ? pt_launch_variant<MODE, true, true>(a, variant, false, n_cu, stream, grid, launch) : pt_launch_variant<MODE, false, true>(a, variant, false, n_cu, stream, grid, launch);
+    return stats ? pt_launch_variant<MODE, true, false>(a, variant, false, n_cu, stream, grid, launch) : pt_launch_variant<MODE, false, false>(a, variant, false, n_cu, stream, grid, launch);
 }

@@ -81,6 +81,8 @@ inline bool pt_interpreter_forced() {
 #endif
 }
 
+enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
+
 struct PtRenderArgs {
     PtSceneView scene;
     PtCamera cam;
@@ -106,7 +108,8 @@ struct PtRenderArgs {
     uint32_t* stack_spill;           // traversal-stack entries beyond the LDS part, entry x n_lanes
     int32_t stack_lds_cap;           // entries per lane kept in LDS; the rest (up to scene.stack_cap) in stack_spill
     int32_t park_slots;              // parked recursion frames per lane kept in LDS (0 or 1; selects the PARK instantiation); older ones in `spill`
-    int32_t four_waves;              // park_slots == 0 only: the instantiation compiled for 4 waves per SIMD (pt_render_kernel.h, VAR = 2)
+    int32_t four_waves;              // the instantiation compiled for 4 waves per SIMD (scenes without reflective materials only)
+    int32_t run_variant;             // PT_RUN_* (pt_render_kernel.h): which kernel pt_render_common launches
     unsigned int* work_counter;
     unsigned int* overflow_flag;     // set to 1 by any lane that runs out of traversal stack
     uint32_t work_div;               // a wavefront takes (remaining items / work_div) items from work_counter at a time

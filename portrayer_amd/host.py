@@ -19,7 +19,7 @@ _dp, _ip, _up, _u64p, _u8p = H._dp, H._ip, H._up, H._u64p, H._u8p
 
 EXPORTS = ["ph_last_error", "ph_scene_create", "ph_example_scene", "ph_scene_destroy", "ph_scene_counts", "ph_scene_export", "ph_scene_export_textures",
            "ph_scene_flatten", "ph_scene_kdtree", "ph_camera", "ph_obj_load", "ph_renderer_create", "ph_renderer_destroy",
-           "ph_renderer_context", "ph_renderer_ranks", "ph_renderer_prepare_ms", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write", "ph_image_read", "ph_scene_graph"]
+           "ph_renderer_context", "ph_renderer_ranks", "ph_renderer_node", "ph_renderer_prepare_ms", "ph_renderer_render", "ph_example_render_to_png", "ph_png_read", "ph_png_write", "ph_image_read", "ph_scene_graph"]
 
 
 class PortrayerHostError(RuntimeError):
@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
         l.ph_renderer_destroy.restype = None; l.ph_renderer_destroy.argtypes = [vp]
         l.ph_renderer_context.restype = vp; l.ph_renderer_context.argtypes = [vp]
         l.ph_renderer_ranks.restype = C.c_int; l.ph_renderer_ranks.argtypes = [vp]
+        l.ph_renderer_node.restype = vp; l.ph_renderer_node.argtypes = [vp]
         l.ph_renderer_prepare_ms.restype = C.c_int; l.ph_renderer_prepare_ms.argtypes = [vp, _dp]
         l.ph_renderer_render.restype = C.c_int
         l.ph_renderer_render.argtypes = [vp, _dp, C.POINTER(H.PtRenderParams), _dp, _u8p, _dp, C.POINTER(H.PtStats)]
@@ -260,6 +261,11 @@ class Renderer:
     @property
     def ranks(self) -> int:
         return int(lib().ph_renderer_ranks(self._h))
+
+    @property
+    def node(self):
+        """The pt_node behind this renderer when PORTRAYER_GPUS / PORTRAYER_DEVICES spread it over several ranks, else None."""
+        return lib().ph_renderer_node(self._h)
 
     def prepare_ms(self) -> dict:
         out = np.zeros(5)

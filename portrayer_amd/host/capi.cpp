@@ -496,6 +496,7 @@ extern "C" int ph_renderer_create(const ph_scene* s, int traverse, int kd_depth,
 }
 extern "C" void ph_renderer_destroy(ph_renderer* r) { delete r; }
 extern "C" pt_context* ph_renderer_context(ph_renderer* r) { return r ? r->r->context() : nullptr; }
+extern "C" pt_node* ph_renderer_node(ph_renderer* r) { return r ? r->r->node() : nullptr; }
 extern "C" int ph_renderer_ranks(ph_renderer* r) { return !r ? 0 : (r->r->node() ? pt_node_ranks(r->r->node()) : 1); }
 extern "C" int ph_renderer_prepare_ms(ph_renderer* r, double out[5]) {
     if (!r || !out) return bad("null argument");

@@ -11,7 +11,7 @@ dst = os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)  # gpurun merges every call's output into the same directory: take the last run's file
 shutil.copy(newest(f"{src}/trace/*/*_kernel_stats.csv"), f"{dst}/{tag}_kernel_stats.csv")
-timed = r"pt_render_kernel<\d+, false,"  # the timed kernel (STATS = false), not the counting launch
+timed = r"pt_render(_simple)?_kernel<\d+, false,"  # the timed kernel (STATS = false), not the counting launch
 out = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
     for f in [newest(f"{src}/{d}/*/*_counter_collection.csv")]:
@@ -36,6 +36,7 @@ t = json.load(open(tpath)) if os.path.exists(tpath) else {}
 # FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE reads half of a wide coalesced read on gfx950 (MI355X guide, HBM section)
 t[key] = dict(derived, hbm_bytes_per_launch=(2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0, fetch_size_kb=g("FETCH_SIZE"), write_size_kb=g("WRITE_SIZE"),
               kernel=out["kernel"], kernel_trace_avg_ms=ms,
+              valu_issue_frac=g("SQ_THREAD_CYCLES_VALU") / (ms * 1e-3 * 39.3e12), insts_valu_per_launch=g("SQ_INSTS_VALU"),
               source=f"profiles/{rnd}/{tag}_pmc.json (rocprofv3 --pmc passes, one counter group per pass, bench.py --steps 3 --no-extras)")
 json.dump(t, open(tpath, "w"), indent=1)
 print(json.dumps(t[key], indent=1))

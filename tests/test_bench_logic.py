@@ -1,5 +1,6 @@
-"""bench.py's bookkeeping that needs no GPU: which committed rocprofv3 profile a run may quote (the kernel variant is part of
-what was profiled), that every profile it can quote is actually committed, and the SURVEY 8(d) byte / flop accounting."""
+"""bench.py's bookkeeping that needs no GPU: which committed rocprofv3 profile a run may quote (only one of the very kernel
+instantiation that is running), that every profile it can quote is actually committed, the SURVEY 8(d) byte / operation
+accounting, and the shape of the roofline block."""
 import importlib.util
 import json
 import os
@@ -19,8 +20,6 @@ def bench():
 
 def test_committed_profiles_exist_and_are_complete():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert {"big-scene/flat/gpus1", "big-scene/hier/gpus1", "big-scene/kd/gpus1", "big-soup@1920x1080x64/flat/gpus1", "mirror@1920x1080x64/flat/gpus1",
-            "aquarium/flat/gpus1", "big-scene/flat/gpus1/waves3"} <= set(t)
     for key, e in t.items():
         for f in ("hbm_bytes_per_launch", "fetch_size_kb", "write_size_kb", "lanes_active", "valu_busy", "kernel", "kernel_trace_avg_ms", "source"):
             assert f in e, (key, f)
@@ -29,32 +28,44 @@ def test_committed_profiles_exist_and_are_complete():
         assert os.path.exists(os.path.join(ROOT, path)), path
         assert os.path.exists(os.path.join(ROOT, path.replace("_pmc.json", "_kernel_stats.csv")))
         assert 0 < e["lanes_active"] <= 64 and 0 < e["valu_busy"] <= 1
-        assert "pt_render_kernel<" in e["kernel"] and ", false," in e["kernel"], "the timed kernel, not the counting launch"
+        assert "pt_render" in e["kernel"] and ", false," in e["kernel"], "the timed kernel, not the counting launch"
 
 
-def test_profile_lookup_follows_the_kernel_variant(bench, monkeypatch):
-    monkeypatch.delenv("PORTRAYER_WAVES", raising=False)
-    default = bench.measured_profile("big-scene", "flat", 1)
-    assert ", 2>" in default["kernel"], "the scene's default kernel is the 128-register one"
-    monkeypatch.setenv("PORTRAYER_WAVES", "3")
-    three = bench.measured_profile("big-scene", "flat", 1)
-    assert ", 0>" in three["kernel"] and three["hbm_bytes_per_launch"] < default["hbm_bytes_per_launch"] / 10
-    assert ", 0>" in bench.measured_profile("big-scene", "hier", 1)["kernel"]
-    monkeypatch.setenv("PORTRAYER_WAVES", "4")
-    assert bench.measured_profile("big-scene", "flat", 1) == default
-    assert bench.measured_profile("big-scene", "hier", 1) is None, "no profile of the hierarchical scene on the 4-wave kernel is committed"
-    monkeypatch.delenv("PORTRAYER_WAVES")
-    assert bench.measured_profile("big-scene", "flat", 8) is None and bench.measured_profile("no-such-workload", "flat", 1) is None
+def test_kernel_name_follows_pt_stats(bench):
+    assert bench.kernel_name({"kernel_mode": 3, "kernel_variant": 4}) == "void pt_render_simple_kernel<3, false, false, 4>(PtRenderArgs)"
+    assert bench.kernel_name({"kernel_mode": 1, "kernel_variant": 3 | 128}) == "void pt_render_simple_kernel<1, false, true, 3>(PtRenderArgs)"
+    assert bench.kernel_name({"kernel_mode": 4, "kernel_variant": 3 | 16 | 32 | 128}) == "void pt_render_kernel<4, false, true, 1>(PtRenderArgs)"
+    assert bench.kernel_name({"kernel_mode": 3, "kernel_variant": 4 | 16}) == "void pt_render_kernel<3, false, false, 2>(PtRenderArgs)"
+    assert bench.kernel_name({"kernel_mode": 7, "kernel_variant": 3 | 16}) == "void pt_render_kernel<7, false, false, 0>(PtRenderArgs)"
 
 
-def test_roofline_block_is_null_without_a_profile(bench, monkeypatch):
-    monkeypatch.delenv("PORTRAYER_WAVES", raising=False)
+def test_a_profile_is_quoted_only_for_the_kernel_that_runs(bench):
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for key, e in t.items():
+        base = key.rsplit("/waves", 1)[0]
+        assert bench.measured_profile(base, e["kernel"]) is not None
+        assert bench.measured_profile(base, "void some_other_kernel<1>(PtRenderArgs)") is None
+    assert bench.measured_profile("no-such-workload/flat/gpus1", "void pt_render_simple_kernel<3, false, false, 4>(PtRenderArgs)") is None
+
+
+def test_roofline_block_shape(bench):
     counts = {"primary": 100, "shadow": 200, "reflect": 0, "refract": 0, "hits": 70, "n_inner": 4000, "n_leaf": 500, "n_analytic": 490, "n_tri": 0, "n_bbox": 0}
-    r = bench.roofline_block("no-such-workload", "flat", 1, True, 1.0e9, 0.01, 6000.0, counts, counts, 300, 3)
-    assert r["achieved"] is None and r["frac"] is None and r["traffic"] is None and "no PMC profile" in r["basis"]
-    assert r["peak"] == 6000.0 and r["spec_peak"] == 8000.0 and r["algorithmic"]["GBps"] == pytest.approx(100.0)
-    r = bench.roofline_block("big-scene", "flat", 1, True, 1.0e9, 0.0175, 6000.0, counts, counts, 300, 3)
-    assert r["traffic"] > 0 and r["frac"] == pytest.approx(r["traffic"] / 0.0175 / 1e9 / 6000.0)
+    st = dict(counts, kernel_mode=3, kernel_variant=4)
+    r = bench.roofline_block("no-such-workload/flat/gpus1", True, st, 1.0e9, 0.01, 6000.0, counts, counts, 300, 3, "flat", 5.0e8)
+    f64, f32, flops = bench.algorithmic_ops(counts, 3, "flat")
+    assert r["bound"] == "valu" and r["peak"] == 39.3 and r["traffic"] is None
+    assert r["achieved"] == pytest.approx((f64 + 0.5 * f32) / 0.01 / 1e12) and r["frac"] == pytest.approx(r["achieved"] / 39.3)
+    assert r["hbm"]["needed_bytes"] == 5.0e8 and r["hbm"]["measured_bytes"] is None and r["hbm"]["waste_ratio"] is None and "no PMC profile" in r["hbm"]["profile"]
+    assert r["algorithmic"]["GBps"] == pytest.approx(100.0) and r["kernel"].startswith("void pt_render_simple_kernel<3, false, false, 4>")
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for key, e in t.items():
+        if "/waves" in key or "pt_render_simple_kernel<" not in e["kernel"]:
+            continue
+        mode, tex, waves = e["kernel"].split("<")[1].split(">")[0].replace(" ", "").split(",")[0::2] + [None]
+        st = dict(counts, kernel_mode=int(mode), kernel_variant=int(e["kernel"].split(",")[-1].split(">")[0]))
+        r = bench.roofline_block(key, True, st, 1.0e9, 0.0175, 6000.0, counts, counts, 300, 3, "flat", 5.0e8)
+        assert r["traffic"] == e["hbm_bytes_per_launch"] and r["hbm"]["waste_ratio"] == pytest.approx(r["traffic"] / 5.0e8)
+        assert r["hbm"]["GBps"] == pytest.approx(r["traffic"] / 0.0175 / 1e9)
 
 
 def test_survey_accounting(bench):
@@ -62,4 +73,7 @@ def test_survey_accounting(bench):
     rays = 33
     assert bench.algorithmic_bytes(st, 3, 100, "flat") == 56 * rays + 56 * 400 + 104 * 50 + 72 * 30 + 48 * 5 + 9 * (168 + 80 + 360) + 2700
     assert bench.algorithmic_bytes(st, 3, 100, "kd") == bench.algorithmic_bytes(st, 3, 100, "flat") - 40 * 400
-    assert bench.algorithmic_flops(st, 3, "flat") == 48 * 400 + 90 * 50 + 50 * 30 + 126 * 5 + 9 * (60 + 129)
+    f64, f32, flops = bench.algorithmic_ops(st, 3, "flat")
+    assert f64 == 90 * 50 + 50 * 30 + 126 * 5 + 9 * (60 + 129) and f32 == 36 * 400 and flops == f64 + 48 * 400
+    f64k, f32k, flopsk = bench.algorithmic_ops(st, 3, "kd")
+    assert f64k == f64 + 9 * 400 and f32k == 0 and flopsk == f64k

@@ -197,3 +197,45 @@ def test_host_renderer_on_a_node(host, H, monkeypatch):
     b, _, _ = r4.render(sc.camera, w, h, bg, samples=2, seed=1, sample_mode=H.SAMPLE_RNG, want_linear=False)
     r4.close()
     assert np.array_equal(a, b)
+
+
+def _bench_line(*args):
+    """bench.py as the driver starts it (a subprocess; with --gpus N > 1 it spawns its own rank processes), the JSON line parsed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--steps", "2", "--warmup", "1", *args],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_ranks_go_through_pt_node():
+    """`bench.py --gpus 2` times the product's own multi-GPU path: rank 0 drives pt_node_render_resident, the JSON line says which
+    communicator carried the frame. Two ranks on one GPU here (device-to-device copies instead of RCCL: RCCL needs distinct GPUs)."""
+    d = _bench_line("--gpus", "2", "--same-device", "--workload", "primitives", "--check")
+    c = d["config"]["collective"]
+    assert d["n_gpus"] == 2 and c["via"].startswith("pt_node_render_resident") and c["ranks_in_group"] == 2 and c["devices"] == [0, 0]
+    assert c["uses_rccl"] is False and c["rank_processes"] == 2
+    assert d["config"]["assembled_image_equals_single_gpu_render"] is True
+    assert d["value"] > 0 and d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1.5
+    assert d["config"]["rays"]["primary"] == 800 * 600
+
+
+def test_bench_two_ranks_via_torch_cross_check():
+    """The same partition with one process per GPU and torch.distributed's gather (gloo here: two ranks share the GPU)."""
+    d = _bench_line("--gpus", "2", "--same-device", "--via", "torch", "--backend", "gloo", "--workload", "primitives", "--check")
+    c = d["config"]["collective"]
+    assert c["via"].startswith("torch.distributed") and c["ranks_in_group"] == 2
+    assert d["config"]["assembled_image_equals_single_gpu_render"] is True
+
+
+def test_bench_single_gpu_line_carries_the_contract_fields():
+    d = _bench_line("--workload", "cows")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"].startswith("T lane-ops/s") and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert "pt_render_simple_kernel<1, false, false, 3>" in r["kernel"], "macho-cows: meshes, nothing reflective, 3 waves"
+    assert r["hbm"]["needed_bytes"] > 0 and d["config"]["collective"] is None
