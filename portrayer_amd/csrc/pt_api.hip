@@ -92,15 +92,15 @@ __global__ void __launch_bounds__(256) pt_collapse4_kernel(const PtBvhNode* __re
     float lo[4][3], hi[4][3];
     uint32_t child[4];
     int k = 0;
-    auto put = [&](const float* l, const float* h, uint32_t c) {
-        for (int ax = 0; ax < 3; ax++) { lo[k][ax] = l[ax]; hi[k][ax] = h[ax]; }
-        child[k] = c;
+    auto put = [&](const PtBvhNode& nd, int which) {
+        pt_node_get_box(nd, which, lo[k], hi[k]);
+        child[k] = which ? nd.child1 : nd.child0;
         k++;
     };
     auto inner = [&](uint32_t c) { return c != PT_REF_EMPTY && !(c & PT_REF_LEAF) && c < n; };
     if (by_area) {
-        if (a.child0 != PT_REF_EMPTY) put(a.lo0, a.hi0, a.child0);
-        if (a.child1 != PT_REF_EMPTY) put(a.lo1, a.hi1, a.child1);
+        if (a.child0 != PT_REF_EMPTY) put(a, 0);
+        if (a.child1 != PT_REF_EMPTY) put(a, 1);
         while (k < 4) {
             int best = -1;
             float best_area = -1.0f;
@@ -115,21 +115,22 @@ __global__ void __launch_bounds__(256) pt_collapse4_kernel(const PtBvhNode* __re
             const int n_kids = (c.child0 != PT_REF_EMPTY) + (c.child1 != PT_REF_EMPTY);
             if (n_kids == 0) { child[best] = child[k - 1]; for (int ax = 0; ax < 3; ax++) { lo[best][ax] = lo[k - 1][ax]; hi[best][ax] = hi[k - 1][ax]; } k--; continue; }
             // the first child takes the opened entry's place, the second goes to the end
-            const bool first0 = c.child0 != PT_REF_EMPTY;
-            for (int ax = 0; ax < 3; ax++) { lo[best][ax] = first0 ? c.lo0[ax] : c.lo1[ax]; hi[best][ax] = first0 ? c.hi0[ax] : c.hi1[ax]; }
-            child[best] = first0 ? c.child0 : c.child1;
-            if (n_kids == 2) put(c.lo1, c.hi1, c.child1);
+            const int first = c.child0 != PT_REF_EMPTY ? 0 : 1;
+            pt_node_get_box(c, first, lo[best], hi[best]);
+            child[best] = first ? c.child1 : c.child0;
+            if (n_kids == 2) put(c, 1);
         }
     } else {
-        auto expand = [&](const float* l, const float* h, uint32_t c0) {
+        auto expand = [&](const PtBvhNode& nd, int which) {
+            const uint32_t c0 = which ? nd.child1 : nd.child0;
             if (c0 == PT_REF_EMPTY) return;
-            if (!inner(c0)) { put(l, h, c0); return; }
+            if (!inner(c0)) { put(nd, which); return; }
             const PtBvhNode c = bvh2[c0];
-            if (c.child0 != PT_REF_EMPTY) put(c.lo0, c.hi0, c.child0);
-            if (c.child1 != PT_REF_EMPTY) put(c.lo1, c.hi1, c.child1);
+            if (c.child0 != PT_REF_EMPTY) put(c, 0);
+            if (c.child1 != PT_REF_EMPTY) put(c, 1);
         };
-        expand(a.lo0, a.hi0, a.child0);
-        expand(a.lo1, a.hi1, a.child1);
+        expand(a, 0);
+        expand(a, 1);
     }
     PtBvh4Node o;
     for (int j = 0; j < 4; j++) {

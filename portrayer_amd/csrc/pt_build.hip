@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(PT_BUILD_BLOCK) pt_ploc_merge(uint32_t m, cons
         o.leaf_count[node] = ca + cb;
     } else {
         PtBvhNode nd;
-        for (int k = 0; k < 3; k++) { nd.lo0[k] = ba.v[k]; nd.hi0[k] = ba.v[3 + k]; nd.lo1[k] = bb.v[k]; nd.hi1[k] = bb.v[3 + k]; }
+        for (int k = 0; k < 3; k++) { nd.lo[k][0] = ba.v[k]; nd.hi[k][0] = ba.v[3 + k]; nd.lo[k][1] = bb.v[k]; nd.hi[k][1] = bb.v[3 + k]; }
         nd.child0 = pt_ploc_ref(o, a);
         nd.child1 = pt_ploc_ref(o, b);
         nd.pad[0] = nd.pad[1] = 0u;

@@ -143,8 +143,8 @@ struct Builder {
         PtBvhRef r = build(mid, e, level + 1);
         PtBvhNode& nd = (*nodes)[idx];
         for (int k = 0; k < 3; k++) {
-            nd.lo0[k] = round_down(l.box.lo[k]); nd.hi0[k] = round_up(l.box.hi[k]);
-            nd.lo1[k] = round_down(r.box.lo[k]); nd.hi1[k] = round_up(r.box.hi[k]);
+            nd.lo[k][0] = round_down(l.box.lo[k]); nd.hi[k][0] = round_up(l.box.hi[k]);
+            nd.lo[k][1] = round_down(r.box.lo[k]); nd.hi[k][1] = round_up(r.box.hi[k]);
         }
         nd.child0 = l.child; nd.child1 = r.child; nd.pad[0] = nd.pad[1] = 0;
         PtBvhRef out;

@@ -30,10 +30,17 @@ enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2, PT_MODE_FLAT_NOMESH = 3, PT_MODE_FLAT_K
 // own arithmetic may be single precision as long as it never rejects a box the f64 ray touches
 // (pt_slab32 in pt_trace.h carries the error bounds).
 struct PtBvhNode {
-    float lo0[3], hi0[3], lo1[3], hi1[3];
+    float lo[3][2], hi[3][2];  // [axis][child]: the two children's planes of one axis side by side, so that a wave-uniform walk
+                               // feeds one packed f32 fma with the pair straight from scalar registers (pt_trace.h: pt_slab_pk2)
     uint32_t child0, child1;
     uint32_t pad[2];
-};  // 64 bytes = four 16-byte loads
+};  // 64 bytes = one s_load_dwordx16 / four 16-byte loads
+PT_HD void pt_node_get_box(const PtBvhNode& n, int child, float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; k++) { lo[k] = n.lo[k][child]; hi[k] = n.hi[k][child]; }
+}
+PT_HD void pt_node_set_box(PtBvhNode& n, int child, const float lo[3], const float hi[3]) {
+    for (int k = 0; k < 3; k++) { n.lo[k][child] = lo[k]; n.hi[k][child] = hi[k]; }
+}
 
 // What the walks read: FOUR children per record. Built from the two-child tree by pulling every inner child's
 // own two children up one level (pt_collapse4_kernel): node i of this array holds the grandchildren of two-child

@@ -264,9 +264,10 @@ PT_HD bool pt_bvh2_walk(const PtBvhNode* nodes, uint32_t root, const PtRay& r, c
             PT_WAVE_COUNT(4);
             // tmax rounded up: (float) rounds to nearest, one more relative step covers it (inf stays inf)
             float tm = (float)tmax; tm = tm + fabsf(tm) * 2.4e-7f;
-            float t0, t1;
-            bool h0 = pt_slab32(n.lo0, n.hi0, q, tm, &t0);
-            bool h1 = pt_slab32(n.lo1, n.hi1, q, tm, &t1);
+            float t0, t1, lo0[3], hi0[3], lo1[3], hi1[3];
+            pt_node_get_box(n, 0, lo0, hi0); pt_node_get_box(n, 1, lo1, hi1);
+            bool h0 = pt_slab32(lo0, hi0, q, tm, &t0);
+            bool h1 = pt_slab32(lo1, hi1, q, tm, &t1);
             uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
@@ -526,9 +527,10 @@ struct PtBvhWalker {
             if (STATS) cnt->n_inner++;
             PT_WAVE_COUNT(4);
             float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;
-            float t0, t1;
-            bool h0 = pt_slab32(n.lo0, n.hi0, q, tm, &t0);
-            bool h1 = pt_slab32(n.lo1, n.hi1, q, tm, &t1);
+            float t0, t1, lo0[3], hi0[3], lo1[3], hi1[3];
+            pt_node_get_box(n, 0, lo0, hi0); pt_node_get_box(n, 1, lo1, hi1);
+            bool h0 = pt_slab32(lo0, hi0, q, tm, &t0);
+            bool h1 = pt_slab32(lo1, hi1, q, tm, &t1);
             uint32_t c0 = n.child0, c1 = n.child1;
             if (h0 && h1) {
                 bool swap = t1 < t0;
@@ -908,6 +910,168 @@ PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, cons
     return r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The slab test of the wave-uniform walks: both children of a node in one go, the node's planes as SCALAR operands.
+//
+// Per lane and axis two pairs of f32 constants: (i_n, c_n) for the plane through which the ray ENTERS a slab on that axis and
+// (i_f, c_f) for the plane through which it LEAVES - the lower plane first when the direction is positive, the upper one first
+// when it is negative. A plane coordinate P gives the parameter fma(P, i, c) ~ (P - o) / d. The constants are rounded so that
+// every error makes the overlap LONGER (the walk may only err towards testing more candidates):
+//     i0  = rcp((float)d)                        relative error < 2^-22.4 (conversion 2^-24, v_rcp_f32 one ulp)
+//     i_n = i0 (1 - 2^-21),  i_f = i0 (1 + 2^-21)    so |i_n| < |1 / d| < |i_f| by at least 2^-23 relative, whatever i0's error
+//     c_n = fl(-o i_n) - margin,  c_f = fl(-o i_f) + margin   (the product in f64 from the f64 origin; margin = 2^-22 relative
+//                                                              + 1e-37: more than the conversion's rounding)
+// Entering: fma(P, i_n, c_n) = (P - o) i_n - m before its one rounding; for a positive parameter T = (P - o) / d that is at most
+// T (1 - 2^-23), which the fma's rounding (2^-24) cannot lift above T; a negative one stays negative (it is clamped to 0 anyway).
+// Leaving: fma(P, i_f, c_f) >= T (1 + 2^-23) (1 - 2^-24) >= T for T >= 0; a box with T < 0 lies behind the ray and may be rejected.
+// An axis the ray is parallel to (|i0| > 1e18 or NaN - which also keeps every product below FLT_MAX for |coordinates| <= 1e18) is
+// switched off: (0, -inf) and (0, +inf).
+//
+// When the directions of all the wavefront's rays have the same sign on an axis - nearly always: they pass through one pixel, or
+// leave neighbouring points for one light - the scalar unit picks the entering and the leaving plane pair of the node for that
+// axis and a step is 6 packed fmas + 8 min / max + 3 compares for both children. Otherwise (`mixed`) both planes go through both
+// pairs of constants and min / max sort them out per lane.
+// ------------------------------------------------------------------------------------------------
+typedef float pt_f32x2 __attribute__((ext_vector_type(2)));
+struct PtRayPk {
+    pt_f32x2 n[3], f[3];  // per axis (i_n, c_n), (i_f, c_f)
+};
+PT_HD float pt_rcp_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// returns 0: axis switched off, 1: positive direction, 2: negative direction
+PT_HD int pt_raypk_axis(double o, double d, pt_f32x2* n, pt_f32x2* f) {
+    const float i0 = pt_rcp_f32((float)d);
+    if (!(fabsf(i0) <= 1e18f)) {
+        n->x = 0.0f; n->y = -INFINITY; f->x = 0.0f; f->y = INFINITY;
+        return 0;
+    }
+    const float k = 4.76837158203125e-7f;  // 2^-21
+    const float in = i0 - i0 * k, fi = i0 + i0 * k;
+    float cn = (float)(-(o * (double)in)), cf = (float)(-(o * (double)fi));
+    cn = cn - (fabsf(cn) * 2.4e-7f + 1e-37f);
+    cf = cf + (fabsf(cf) * 2.4e-7f + 1e-37f);
+    n->x = in; n->y = cn; f->x = fi; f->y = cf;
+    return i0 < 0.0f ? 2 : 1;
+}
+// Constants of `r` for this lane; *neg / *pos get bit a set when the lane's direction is negative / positive on axis a.
+PT_HD PtRayPk pt_raypk(const PtRay& r, uint32_t* neg, uint32_t* pos) {
+    PtRayPk q;
+    const int sx = pt_raypk_axis(r.o.x, r.d.x, &q.n[0], &q.f[0]);
+    const int sy = pt_raypk_axis(r.o.y, r.d.y, &q.n[1], &q.f[1]);
+    const int sz = pt_raypk_axis(r.o.z, r.d.z, &q.n[2], &q.f[2]);
+    *neg = (sx == 2 ? 1u : 0u) | (sy == 2 ? 2u : 0u) | (sz == 2 ? 4u : 0u);
+    *pos = (sx == 1 ? 1u : 0u) | (sy == 1 ? 2u : 0u) | (sz == 1 ? 4u : 0u);
+    return q;
+}
+// The wavefront's view of its rays' directions: bit a of `neg`: the rays enter slabs of axis a through the upper plane;
+// `mixed`: some axis has rays of both signs among the lanes of `lanes`, the per-lane form of the test is needed.
+struct PtWaveSigns {
+    uint32_t neg;
+    bool mixed;
+};
+PT_HD PtWaveSigns pt_wave_signs(uint32_t neg, uint32_t pos, bool lane_has_ray) {
+    PtWaveSigns w;
+    w.neg = 0; w.mixed = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const bool any_neg = PT_BALLOT(lane_has_ray && ((neg >> a) & 1u)) != 0ull, any_pos = PT_BALLOT(lane_has_ray && ((pos >> a) & 1u)) != 0ull;
+        if (any_neg) w.neg |= 1u << a;
+        if (any_neg && any_pos) w.mixed = true;
+    }
+    return w;
+}
+PT_HD pt_f32x2 pt_pair_f32(uint32_t a, uint32_t b) { pt_f32x2 v; v.x = pt_f32_of(a); v.y = pt_f32_of(b); return v; }
+// packed fma with per-lane constants (i, c) broadcast to both halves: (p.x i + c, p.y i + c)
+PT_HD pt_f32x2 pt_pk_fma_bcast(pt_f32x2 planes, pt_f32x2 ic) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_PK_ASM)
+    pt_f32x2 r;
+    // src1 = ic.x for both halves (op_sel 0 / op_sel_hi 0), src2 = ic.y for both halves (op_sel 1 / op_sel_hi 1)
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "s"(planes), "v"(ic));
+    return r;
+#else
+    pt_f32x2 r;
+    r.x = __builtin_fmaf(planes.x, ic.x, ic.y); r.y = __builtin_fmaf(planes.y, ic.x, ic.y);
+    return r;
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_FCMP_LE(a, b) __builtin_amdgcn_fcmpf((a), (b), 5)  // ordered <=, as a lane mask
+#define PT_FCMP_LT(a, b) __builtin_amdgcn_fcmpf((a), (b), 4)
+#else
+#define PT_FCMP_LE(a, b) (((a) <= (b)) ? 1ull : 0ull)
+#define PT_FCMP_LT(a, b) (((a) < (b)) ? 1ull : 0ull)
+#endif
+// min / max as single instructions: fmaxf / fminf on a value that comes out of inline asm make the compiler canonicalise it first
+// (one v_max x, x per operand - twelve extra instructions per tree step)
+PT_HD float pt_max2_raw(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_PK_ASM)
+    float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return fmaxf(a, b);
+#endif
+}
+PT_HD float pt_min2_raw(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_PK_ASM)
+    float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return fminf(a, b);
+#endif
+}
+PT_HD float pt_max3_zero_raw(float a, float b) {  // max(a, b, 0)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_PK_ASM)
+    float r; asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return fmaxf(fmaxf(a, b), 0.0f);
+#endif
+}
+PT_HD float pt_min3_raw(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_PK_ASM)
+    float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+    return fminf(fminf(a, b), c);
+#endif
+}
+// Both child boxes of node record `v` (PtBvhNode as 16 dwords in scalar registers) against every lane's ray over [0, tm].
+// Out: masks of the lanes whose rays reach child 0 / child 1, and of those that reach child 1 strictly before child 0.
+PT_HD void pt_slab_pk2(const pt_u32x16& v, const PtRayPk& q, const PtWaveSigns& ws, float tm, unsigned long long* m0, unsigned long long* m1,
+                       unsigned long long* one_first) {
+    float tn0, tn1, tf0, tf1;
+    if (!ws.mixed) {
+        // the entering / leaving plane pairs of the two children, picked per axis by the scalar unit
+        const bool nx = ws.neg & 1u, ny = ws.neg & 2u, nz = ws.neg & 4u;
+        const pt_f32x2 ex = nx ? pt_pair_f32(v[6], v[7]) : pt_pair_f32(v[0], v[1]), lx = nx ? pt_pair_f32(v[0], v[1]) : pt_pair_f32(v[6], v[7]);
+        const pt_f32x2 ey = ny ? pt_pair_f32(v[8], v[9]) : pt_pair_f32(v[2], v[3]), ly = ny ? pt_pair_f32(v[2], v[3]) : pt_pair_f32(v[8], v[9]);
+        const pt_f32x2 ez = nz ? pt_pair_f32(v[10], v[11]) : pt_pair_f32(v[4], v[5]), lz = nz ? pt_pair_f32(v[4], v[5]) : pt_pair_f32(v[10], v[11]);
+        const pt_f32x2 ax = pt_pk_fma_bcast(ex, q.n[0]), ay = pt_pk_fma_bcast(ey, q.n[1]), az = pt_pk_fma_bcast(ez, q.n[2]);
+        const pt_f32x2 bx = pt_pk_fma_bcast(lx, q.f[0]), by = pt_pk_fma_bcast(ly, q.f[1]), bz = pt_pk_fma_bcast(lz, q.f[2]);
+        tn0 = pt_max3_zero_raw(pt_max2_raw(ax.x, ay.x), az.x); tn1 = pt_max3_zero_raw(pt_max2_raw(ax.y, ay.y), az.y);
+        tf0 = pt_min3_raw(pt_min2_raw(bx.x, by.x), bz.x, tm); tf1 = pt_min3_raw(pt_min2_raw(bx.y, by.y), bz.y, tm);
+    } else {
+        // rays of both signs on some axis: each lane takes the smaller of the two planes' entering values and the larger of their
+        // leaving values (one of the two is the true one, computed conservatively; the other can only lengthen the overlap)
+        float tn[2] = {0.0f, 0.0f}, tf[2] = {tm, tm};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const pt_f32x2 lo = pt_pair_f32(v[2 * a], v[2 * a + 1]), hi = pt_pair_f32(v[6 + 2 * a], v[6 + 2 * a + 1]);
+            const pt_f32x2 el = pt_pk_fma_bcast(lo, q.n[a]), eh = pt_pk_fma_bcast(hi, q.n[a]);
+            const pt_f32x2 ll = pt_pk_fma_bcast(lo, q.f[a]), lh = pt_pk_fma_bcast(hi, q.f[a]);
+            tn[0] = pt_max2_raw(tn[0], pt_min2_raw(el.x, eh.x)); tn[1] = pt_max2_raw(tn[1], pt_min2_raw(el.y, eh.y));
+            tf[0] = pt_min2_raw(tf[0], pt_max2_raw(ll.x, lh.x)); tf[1] = pt_min2_raw(tf[1], pt_max2_raw(ll.y, lh.y));
+        }
+        tn0 = tn[0]; tn1 = tn[1]; tf0 = tf[0]; tf1 = tf[1];
+    }
+    *m0 = PT_FCMP_LE(tn0, tf0);
+    *m1 = PT_FCMP_LE(tn1, tf1);
+    *one_first = PT_FCMP_LT(tn1, tn0);
+}
+// a lane's exclusive range end as the f32 the slab test compares with, rounded up (inf stays inf)
+PT_HD float pt_tmax32(double t) { float tm = (float)t; return tm + fabsf(tm) * 2.4e-7f; }
+
 // One flattened node against every participating lane's ray; `node` is wave-uniform.
 template <bool STATS, bool HIER>
 PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray, PtHit& best, PtCounters* cnt) {
@@ -966,8 +1130,12 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return;
     const unsigned long long self = 1ull << PT_LANE_ID();
     bool alive = has_ray;               // the lane still wants candidates (a shadow ray stops at its first hit)
+    unsigned long long amask = PT_BALLOT(alive);  // the same as a wave-uniform mask: the slab test's results are masks, never per-lane booleans
     unsigned long long in = ~0ull;      // wave-uniform: lanes whose rays reach the current node's box
-    const PtRay32 q = pt_ray32(ray);
+    uint32_t neg, pos;
+    const PtRayPk q = pt_raypk(ray, &neg, &pos);
+    const PtWaveSigns ws = pt_wave_signs(neg, pos, has_ray);
+    float tm = INFINITY;                 // best.t as the f32 bound of the slab test, rounded up; follows best.t
     uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
     int sp = 0;                          // words on the stack
     constexpr int W = STATS ? 3 : 1;     // per entry: the node, and in the counting build the mask of the lanes that reach it
@@ -977,18 +1145,14 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
         while (!(cur & PT_REF_LEAF)) {
             const pt_u32x16 v = pt_sload16(sc.bvh + cur);
             PT_WAVE_COUNT(4);
-            const bool mine = alive && (!STATS || (in & self));
-            if (STATS && mine) cnt->n_inner++;
-            float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;  // rounded up, like the per-lane walk
-            const float lo0[3] = {pt_f32_of(v[0]), pt_f32_of(v[1]), pt_f32_of(v[2])}, hi0[3] = {pt_f32_of(v[3]), pt_f32_of(v[4]), pt_f32_of(v[5])};
-            const float lo1[3] = {pt_f32_of(v[6]), pt_f32_of(v[7]), pt_f32_of(v[8])}, hi1[3] = {pt_f32_of(v[9]), pt_f32_of(v[10]), pt_f32_of(v[11])};
-            float t0, t1;
-            const bool h0 = pt_slab32(lo0, hi0, q, tm, &t0) && mine;
-            const bool h1 = pt_slab32(lo1, hi1, q, tm, &t1) && mine;
-            const unsigned long long m0 = PT_BALLOT(h0), m1 = PT_BALLOT(h1);
+            const unsigned long long mine = STATS ? (amask & in) : amask;
+            if (STATS && (mine & self)) cnt->n_inner++;
+            unsigned long long m0, m1, one_first;
+            pt_slab_pk2(v, q, ws, tm, &m0, &m1, &one_first);
+            m0 &= mine; m1 &= mine;
             const uint32_t c0 = v[12], c1 = v[13];
             if (m0 && m1) {
-                const unsigned long long second_first = PT_BALLOT(h1 && (!h0 || t1 < t0));  // lanes that would enter child 1 first
+                const unsigned long long second_first = m1 & (~m0 | one_first);  // lanes that would enter child 1 first
                 const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
                 if (sp + W > words) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1020,10 +1184,14 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
             const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
             if (alive && (!STATS || (in & self))) {
                 if (STATS) cnt->n_leaf++;
-                if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, best, cnt) && any) alive = false;
+                if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, best, cnt)) {
+                    tm = pt_tmax32(best.t);
+                    if (any) alive = false;
+                }
             }
         }
-        if (!PT_BALLOT(alive)) return;
+        amask = PT_BALLOT(alive);
+        if (!amask) return;
         if (sp == 0) return;
         sp -= W;
         cur = PT_UNIFORM_U32(slot(sp));
@@ -1046,8 +1214,12 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return;
     bool alive = has_ray;     // the lane still wants candidates
     bool part = has_ray;      // ... and takes part in the tree being walked (inside a mesh: its ray passed the mesh's box test)
+    unsigned long long pmask = PT_BALLOT(alive && part);  // the lanes the slab test's results count for, as a wave-uniform mask
     PtRay local = ray;        // the ray in the space of the tree being walked
-    PtRay32 q = pt_ray32(ray);
+    uint32_t neg, pos;
+    PtRayPk q = pt_raypk(ray, &neg, &pos);
+    PtWaveSigns ws = pt_wave_signs(neg, pos, has_ray);
+    float tm = INFINITY;      // best.t as the f32 bound of the slab test (t means the same in every space, ray.rs:130-135)
     uint32_t inst = PT_NO_HIT;  // wave-uniform: flat node of the mesh instance being walked
     uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
     int sp = 0;
@@ -1065,18 +1237,13 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
         while (!(cur & PT_REF_LEAF)) {
             const pt_u32x16 v = pt_sload16(sc.bvh + cur);
             PT_WAVE_COUNT(4);
-            const bool mine = alive && part;
-            if (STATS && mine) cnt->n_inner++;
-            float tm = (float)best.t; tm = tm + fabsf(tm) * 2.4e-7f;
-            const float lo0[3] = {pt_f32_of(v[0]), pt_f32_of(v[1]), pt_f32_of(v[2])}, hi0[3] = {pt_f32_of(v[3]), pt_f32_of(v[4]), pt_f32_of(v[5])};
-            const float lo1[3] = {pt_f32_of(v[6]), pt_f32_of(v[7]), pt_f32_of(v[8])}, hi1[3] = {pt_f32_of(v[9]), pt_f32_of(v[10]), pt_f32_of(v[11])};
-            float t0, t1;
-            const bool h0 = pt_slab32(lo0, hi0, q, tm, &t0) && mine;
-            const bool h1 = pt_slab32(lo1, hi1, q, tm, &t1) && mine;
-            const unsigned long long m0 = PT_BALLOT(h0), m1 = PT_BALLOT(h1);
+            if (STATS && alive && part) cnt->n_inner++;
+            unsigned long long m0, m1, one_first;
+            pt_slab_pk2(v, q, ws, tm, &m0, &m1, &one_first);
+            m0 &= pmask; m1 &= pmask;
             const uint32_t c0 = v[12], c1 = v[13];
             if (m0 && m1) {
-                const unsigned long long second_first = PT_BALLOT(h1 && (!h0 || t1 < t0));
+                const unsigned long long second_first = m1 & (~m0 | one_first);
                 const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
                 if (sp + 1 > words) { overflowed(); return; }
                 slot(sp) = swap ? c0 : c1; sp++;
@@ -1120,6 +1287,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         if (STATS) cnt->n_tri++;
                         if (pt_triangle_hit(tv, local, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, inst, tri), &tt, &beta, &gamma)) {
                             best.t = tt; best.node = inst; best.sub = tri;
+                            tm = pt_tmax32(tt);
                             if (any) alive = false;
                         }
                     }
@@ -1146,6 +1314,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                                 double t; uint32_t tri = 0;
                                 if (pt_kdmesh_hit<STATS>(sc, *mi, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, 0), lane_stk, 0, &t, &tri, cnt)) {
                                     best.t = t; best.node = node; best.sub = tri;
+                                    tm = pt_tmax32(t);
                                     if (any) alive = false;
                                 }
                             }
@@ -1158,20 +1327,27 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         double bi[12];
                         pt_sload_mat12(mi->bbox_inv, bi);
                         const bool inside = alive && pt_bbox_test_hit(bi, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, 0));
-                        if (!PT_BALLOT(inside)) continue;
+                        const unsigned long long inside_mask = PT_BALLOT(inside);
+                        if (!inside_mask) continue;
                         if (sp + 2 > words) { overflowed(); return; }
                         if (i + 1 < count) { slot(sp) = PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2); sp++; }  // the rest of this leaf
                         slot(sp) = PT_REF_MARKER; sp++;
-                        local = lr; q = pt_ray32(lr); part = inside; inst = node;
+                        local = lr; part = inside; inst = node;
+                        q = pt_raypk(lr, &neg, &pos);
+                        ws = pt_wave_signs(neg, pos, inside);
                         cur = root;
                         entered = true;
                     } else if (alive) {
-                        if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, best, cnt) && any) alive = false;
+                        if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, best, cnt)) {
+                            tm = pt_tmax32(best.t);
+                            if (any) alive = false;
+                        }
                     }
                 }
-                if (entered) continue;
+                if (entered) { pmask = PT_BALLOT(alive && part); continue; }
             }
             if (!PT_BALLOT(alive)) return;
+            pmask = PT_BALLOT(alive && part);
         }
         // the next pending subtree; a marker ends the walk of a mesh instance
         for (;;) {
@@ -1179,7 +1355,10 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
             sp--;
             cur = PT_UNIFORM_U32(slot(sp));
             if (cur != PT_REF_MARKER) break;
-            inst = PT_NO_HIT; local = ray; q = pt_ray32(ray); part = has_ray;
+            inst = PT_NO_HIT; local = ray; part = has_ray;
+            q = pt_raypk(ray, &neg, &pos);
+            ws = pt_wave_signs(neg, pos, alive);
+            pmask = PT_BALLOT(alive && part);
         }
     }
 }

@@ -60,7 +60,15 @@ def main():
                 r = host.Renderer(hs, tr, kd_depth=8)
                 rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=samples, seed=seed, sample_mode=H.SAMPLE_RNG, stats=True)
                 ref = O.render(ps, cam, w, h, samples=samples, seed=seed, jitter=O.JITTER_RNG, mode=om, kd_depth=8)
+                plain, plain_linear, _ = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=samples, seed=seed, sample_mode=H.SAMPLE_RNG)  # the timed (non-counting) instantiation
+                if not np.array_equal(plain, rgb) or not np.array_equal(plain_linear, linear):
+                    bad_total += 1
+                    print(f"MISMATCH seed {seed} {kind} {mode}: the counting and the plain instantiation render different images", flush=True)
                 bad = (rgb != ref.rgb).any(axis=2)
+                lin_bad = (linear.view(np.uint64) != ref.linear.view(np.uint64)).any(axis=2) & ~bad  # the device pow is glibc's: f64 means identical where the pixel is
+                if kind != "textured" and lin_bad.any():
+                    bad_total += int(lin_bad.sum())
+                    print(f"MISMATCH seed {seed} {kind} {mode}: {int(lin_bad.sum())} pixels whose f64 mean differs in the last bits", flush=True)
                 if kind == "textured" and bad.sum() <= 2:  # sphere uv goes through atan2 / acos: a last-bit difference may move a sample across a texel edge
                     tex_edge += int(bad.sum()); bad[:] = False
                 rays_equal = all(st[k] == ref.stats[k] for k in ("primary", "shadow", "reflect", "refract", "hits"))
