@@ -39,6 +39,10 @@ PT_HD void pt_sload_f64(const double* p, double* out) {
 // One ray kind for the whole wavefront: `tracing` lanes carry `ray`; result in `hit` (untouched for the other lanes).
 template <int MODE, bool STATS>
 PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, bool any, PtHit& hit, const PtStackSpill& stk, uint32_t* lds, PtCounters* cnt) {
+#ifdef PT_CYCLES  // profiles/cycles.sh: wave cycles inside the walks -> diag[0], calls -> diag[1]
+    const unsigned long long cyc_t0 = __builtin_readcyclecounter();
+    struct CycEnd { unsigned long long t0; PtCounters* c; __device__ ~CycEnd() { if (STATS && (threadIdx.x & 63u) == 0) { c->diag[0] += __builtin_readcyclecounter() - t0; c->diag[1]++; } } } cyc_end{cyc_t0, cnt};
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t* wave_lds = lds + (threadIdx.x & ~63u);
 #else
@@ -112,6 +116,9 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
             if (w == 0xFFFFFFFFu) break;
         }
 
+#ifdef PT_CYCLES
+        const unsigned long long cyc_item0 = __builtin_readcyclecounter();
+#endif
         // ---- the primary ray of this lane's sample (render.rs:36-41, camera.rs:48-84)
         uint32_t x, y;
         bool mine;
@@ -219,6 +226,9 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
             }
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef PT_CYCLES  // the whole item -> diag[2] (the part outside the walks = diag[2] - diag[0])
+        if (STATS && lane == 0) cnt.diag[2] += __builtin_readcyclecounter() - cyc_item0;
+#endif
     }
     if (STATS) pt_flush_counters(a.counters, cnt);
 }

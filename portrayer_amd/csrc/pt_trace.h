@@ -861,6 +861,24 @@ PT_HD pt_u32x4 pt_sload4(const void* p) {
 #endif
     return v;
 }
+// -DPT_PREFETCH_CHILDREN (experiment): pull a record's cache line into the scalar cache without waiting for it. The destination
+// register stays allocated until the next pt_sload16_after(), whose s_waitcnt also covers this load.
+PT_HD uint32_t pt_sprefetch(const void* p) {
+    uint32_t v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(pt_uniform_ptr(p)) : "memory");
+#endif
+    return v;
+}
+PT_HD pt_u32x16 pt_sload16_after(const void* p, uint32_t dep0, uint32_t dep1) {
+    pt_u32x16 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pt_uniform_ptr(p)), "s"(dep0), "s"(dep1) : "memory");
+#else
+    v = *static_cast<const pt_u32x16*>(p);
+#endif
+    return v;
+}
 PT_HD double pt_f64_of(uint32_t lo, uint32_t hi) {
     union { double d; uint32_t u[2]; } c;
     c.u[0] = lo; c.u[1] = hi;
@@ -1141,9 +1159,18 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     constexpr int W = STATS ? 3 : 1;     // per entry: the node, and in the counting build the mask of the lanes that reach it
     auto slot = [&](int k) -> uint32_t& { return wstack[(k >> 6) * PT_BLOCK + (k & 63)]; };
     const int words = wcap * 64 < W * sc.stack_cap ? wcap * 64 : W * sc.stack_cap;  // scene.stack_cap entries, if the LDS columns hold them
+#ifdef PT_PREFETCH_CHILDREN
+    uint32_t pf0 = 0, pf1 = 0;
+#endif
     for (;;) {
         while (!(cur & PT_REF_LEAF)) {
+#ifdef PT_PREFETCH_CHILDREN
+            const pt_u32x16 v = pt_sload16_after(sc.bvh + cur, pf0, pf1);
+            pf0 = pt_sprefetch((v[12] & PT_REF_LEAF) ? (const void*)(sc.inv + 12 * (size_t)((v[12] & ~PT_REF_LEAF) >> 3)) : (const void*)(sc.bvh + v[12]));
+            pf1 = pt_sprefetch((v[13] & PT_REF_LEAF) ? (const void*)(sc.inv + 12 * (size_t)((v[13] & ~PT_REF_LEAF) >> 3)) : (const void*)(sc.bvh + v[13]));
+#else
             const pt_u32x16 v = pt_sload16(sc.bvh + cur);
+#endif
             PT_WAVE_COUNT(4);
             const unsigned long long mine = STATS ? (amask & in) : amask;
             if (STATS && (mine & self)) cnt->n_inner++;
@@ -1180,6 +1207,8 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
         }
         const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
         PT_WAVE_COUNT(5);
+        {
+        PT_CYC_BEGIN();
         for (uint32_t i = 0; i < count; i++) {
             const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
             if (alive && (!STATS || (in & self))) {
@@ -1189,6 +1218,8 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
                     if (any) alive = false;
                 }
             }
+        }
+        PT_CYC_END(5);
         }
         amask = PT_BALLOT(alive);
         if (!amask) return;

@@ -8,7 +8,9 @@ for BARGS in "$@"; do
 PT_DUMP_COUNTERS=1 python3 bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0 $BARGS 2>&1 | grep "^counters" | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().split(' ', 1)[1]); g = d['diag']
-tot = g[0] + g[2]
-print('%-50s interpreter %4.1f %%  walk %4.1f %% (leaf tests %4.1f %% of all)   %.0f cycles per loop iteration' % ('$BARGS', 100 * g[2] / tot, 100 * g[0] / tot, 100 * g[5] / tot, tot / max(g[1], 1)))"
+# interpreter kernel: diag[2] = interpreter cycles, diag[0] = walk cycles; straight-line kernel: diag[2] = whole items, diag[0] = walks inside them
+line = d.get('kernel_variant', 16) & 16 == 0
+tot = g[2] if line else g[0] + g[2]
+print('%-50s outside the walks %4.1f %%  walks %4.1f %% (leaf tests %4.1f %% of all, tree steps %4.1f %%)   %.0f wave cycles per walk' % ('$BARGS', 100 * (tot - g[0]) / tot, 100 * g[0] / tot, 100 * g[5] / tot, 100 * (g[0] - g[5]) / tot, g[0] / max(g[1], 1)))"
 done
 cp /tmp/libportrayer_hip.so.keep portrayer_amd/libportrayer_hip.so

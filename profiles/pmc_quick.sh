@@ -11,7 +11,7 @@ import csv,glob,collections,re
 f=glob.glob('$OUT/*/*_counter_collection.csv')
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open(f[0])):
-    if re.search(r'pt_render_kernel<\d+, false,', r['Kernel_Name']):
+    if re.search(r'pt_render(_simple)?_kernel<\d+, false,', r['Kernel_Name']):
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in sorted(agg.items()): print('%-28s %.4g' % (k, sum(v)/len(v)))
 PY
