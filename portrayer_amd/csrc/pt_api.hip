@@ -611,7 +611,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     {   // tree arrays: the host-built part first, then room for the device-built mesh trees
         size_t n_nodes = bvh.size(), n_items = items.size();
         for (const DeviceMesh& dm : device_meshes) { n_nodes += PT_DEVICE_TREE_NODES(dm.count); n_items += PT_DEVICE_TREE_ITEMS(dm.count, blas_leaf); }
-        if (n_items >= (1u << 28) || n_nodes >= (1u << 31)) return pt_fail(c, PT_ERR_SCENE, "too many triangles for the 32-bit tree references");
+        if (n_items >= (1u << 28) || n_nodes >= (1u << 26)) return pt_fail(c, PT_ERR_SCENE, "too many triangles for the 32-bit tree references (a node is addressed by a 32-bit byte offset: 2^26 nodes)");
         if ((rc = pt_reserve(c, c->bvh, n_nodes * sizeof(PtBvhNode))) || (rc = pt_reserve(c, c->bvh_items, n_items * sizeof(uint32_t)))) return rc;
         if (!bvh.empty()) PT_HIP(c, hipMemcpy(c->bvh.p, bvh.data(), bvh.size() * sizeof(PtBvhNode), hipMemcpyHostToDevice));
         if (!items.empty()) PT_HIP(c, hipMemcpy(c->bvh_items.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -50,6 +50,8 @@ __host__ __device__ inline size_t pt_render_lds_bytes(int stack_lds_cap, bool te
     return (size_t)stack_lds_cap * PT_BLOCK * 4 + (size_t)(PT_LDS_FRAME_F64 + park_slots * PT_PARK_F64) * PT_BLOCK * 8;
 }
 
+#include "pt_render_simple.h"
+
 template <int MODE, bool STATS, bool TEX, int VAR>
 __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(PtRenderArgs a) {
     constexpr int PARK = VAR == 1 ? 1 : 0;
@@ -153,32 +155,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
                 if (tracing) { cnt.diag[1]++; if (L.ray_any) cnt.diag[7]++; }
             }
 #endif
-#ifndef PT_NO_PACKET
-            // One walk per wavefront (pt_trace_packet / pt_trace_packet_mesh; every lane calls it) in the flat_scene and hierarchical
-            // semantics. The wavefront's stack takes the LAST rows of its LDS columns where lanes also need a stack of their own
-            // (KDMesh trees), all of them otherwise. The k-d tree semantics keep the per-lane walk (per-ray ranges and order).
-            if (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) {
-                if (__any(tracing))
-                    pt_trace_packet<STATS, MODE == PT_MODE_HIER_NOMESH>(a.scene, L.ray, tracing, L.ray_any, hit, pt_lds + (threadIdx.x & ~63u), a.stack_lds_cap,
-                                                                       a.overflow_flag, &cnt);
-            } else if (MODE == PT_MODE_FLAT) {
-                if (__any(tracing))
-                    pt_trace_packet_mesh<STATS, false, false>(a.scene, L.ray, tracing, L.ray_any, hit, pt_lds + (threadIdx.x & ~63u), a.stack_lds_cap, stk,
-                                                              a.overflow_flag, &cnt);
-            } else if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
-                if (__any(tracing)) {
-                    const int rows = a.stack_lds_cap >= 16 ? 8 : (a.stack_lds_cap >= 8 ? 3 : (a.stack_lds_cap >= 4 ? 2 : 1));  // of the wavefront's stack (64 entries each); the lanes' own stacks get the rest
-                    PtStackSpill lane_stk = stk;
-                    lane_stk.cap = a.stack_lds_cap - rows;
-                    pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, L.ray, tracing, L.ray_any, hit,
-                                                                            pt_lds + (size_t)lane_stk.cap * PT_BLOCK + (threadIdx.x & ~63u), rows, lane_stk,
-                                                                            a.overflow_flag, &cnt);
-                }
-            } else
-#endif
-            if (tracing) pt_trace<MODE, STATS>(a.scene, L.ray, L.ray_any, hit, stk, &cnt);
+            // One walk per wavefront (pt_trace_wave: pt_trace_packet / pt_trace_packet_mesh, every lane calls it) in the flat_scene and
+            // hierarchical semantics; the k-d tree semantics keep the per-lane walk (per-ray ranges and order).
+            if (__any(tracing)) pt_trace_wave<MODE, STATS>(a, L.ray, tracing, L.ray_any, hit, stk, pt_lds, &cnt);
 #ifdef PT_CYCLES
-            if (STATS && lane == 0) { const unsigned long long cyc_c = __builtin_readcyclecounter(); cnt.diag[2] += cyc_b - cyc_a; cnt.diag[0] += cyc_c - cyc_b; cnt.diag[1]++; }
+            if (STATS && lane == 0) cnt.diag[2] += cyc_b - cyc_a;  // the walk's cycles are counted inside pt_trace_wave
 #endif
         }
         // render.rs:36-43 under the summation contract: the chunk's samples in ascending order. A pixel's samples sit
@@ -223,8 +204,6 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 #endif
     if (STATS) pt_flush_counters(a.counters, cnt);
 }
-
-#include "pt_render_simple.h"
 
 // Launch (or, with launch = false, only size) one instantiation. The grid is what is resident: blocks per CU from
 // the occupancy query for this kernel with its LDS. The raised LDS limit and the occupancy are properties of (kernel, device):

@@ -44,20 +44,25 @@ PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, 
     struct CycEnd { unsigned long long t0; PtCounters* c; __device__ ~CycEnd() { if (STATS && (threadIdx.x & 63u) == 0) { c->diag[0] += __builtin_readcyclecounter() - t0; c->diag[1]++; } } } cyc_end{cyc_t0, cnt};
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t* wave_lds = lds + (threadIdx.x & ~63u);
+    const uint32_t wave = threadIdx.x >> 6;
 #else
-    uint32_t* wave_lds = lds;
+    const uint32_t wave = 0;
 #endif
 #ifndef PT_NO_PACKET
+    // The wavefront's stack is a linear region of the block's LDS stack area: all of the wavefront's share where no lane needs a
+    // stack of its own, else the part behind the lanes' rows (KDMesh trees are walked per lane, pt_kdmesh_hit).
     if (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) {
-        pt_trace_packet<STATS, MODE == PT_MODE_HIER_NOMESH>(a.scene, ray, tracing, any, hit, wave_lds, a.stack_lds_cap, a.overflow_flag, cnt);
+        const int words = a.stack_lds_cap * 64;
+        pt_trace_packet<STATS, MODE == PT_MODE_HIER_NOMESH>(a.scene, ray, tracing, any, hit, lds + (size_t)wave * words, words, a.overflow_flag, cnt);
     } else if (MODE == PT_MODE_FLAT) {
-        pt_trace_packet_mesh<STATS, false, false>(a.scene, ray, tracing, any, hit, wave_lds, a.stack_lds_cap, stk, a.overflow_flag, cnt);
+        const int words = a.stack_lds_cap * 64;
+        pt_trace_packet_mesh<STATS, false, false>(a.scene, ray, tracing, any, hit, lds + (size_t)wave * words, words, stk, a.overflow_flag, cnt);
     } else if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
         const int rows = a.stack_lds_cap >= 16 ? 8 : (a.stack_lds_cap >= 8 ? 3 : (a.stack_lds_cap >= 4 ? 2 : 1));  // of the wavefront's stack (64 entries each); the lanes' own stacks get the rest
         PtStackSpill lane_stk = stk;
         lane_stk.cap = a.stack_lds_cap - rows;
-        pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, ray, tracing, any, hit, wave_lds + (size_t)lane_stk.cap * PT_BLOCK, rows, lane_stk, a.overflow_flag, cnt);
+        pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, ray, tracing, any, hit, lds + (size_t)lane_stk.cap * PT_BLOCK + (size_t)wave * rows * 64, rows * 64, lane_stk,
+                                                                a.overflow_flag, cnt);
     } else
 #endif
     if (tracing) pt_trace<MODE, STATS>(a.scene, ray, any, hit, stk, cnt);

@@ -471,6 +471,7 @@ PT_HD bool pt_trace_flat_simple(const PtSceneView& sc, const PtRay& ray, bool an
 // continues in the mesh's tree; popping the marker switches back. Lanes inside a mesh and lanes in
 // the scene tree therefore share the inner-node code instead of waiting for each other.
 #define PT_REF_MARKER 0xFFFFFFFEu
+#define PT_REF_POP 0xFFFFFFFDu     // inside a walk: "take the next pending subtree" (never stored)
 // The walk of the build's two-level bounding-volume tree as a resumable machine: begin() takes a ray, every step() is one
 // round of the "while-while" loop - down through inner nodes to a leaf, the leaf's candidates, the next pending subtree -
 // and returns true once the ray is finished (result in `best`). pt_render_kernel drives it so that a lane whose ray is
@@ -931,10 +932,16 @@ PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, cons
 // ------------------------------------------------------------------------------------------------
 // The slab test of the wave-uniform walks: both children of a node in one go, the node's planes as SCALAR operands.
 //
-// Per lane and axis two pairs of f32 constants: (i_n, c_n) for the plane through which the ray ENTERS a slab on that axis and
-// (i_f, c_f) for the plane through which it LEAVES - the lower plane first when the direction is positive, the upper one first
-// when it is negative. A plane coordinate P gives the parameter fma(P, i, c) ~ (P - o) / d. The constants are rounded so that
-// every error makes the overlap LONGER (the walk may only err towards testing more candidates):
+// What limits these walks is the SCALAR unit - one per CU, shared by its sixteen wavefronts (profiles/r03/notes.md: 5.9e9 scalar
+// against 4.9e9 vector instructions per big-scene frame with the first version of this test, which let the scalar unit pick the
+// entering / leaving plane of every axis) - so everything that can be per-lane arithmetic is, and the scalar side of a step is
+// one load, one block of mask logic and the branches.
+//
+// Per lane and axis two pairs of f32 constants: A = (i, c) applied to the LOWER planes of the children, B = (i, c) applied to the
+// UPPER planes. For a positive direction the ray enters a slab through the lower plane, so A holds the "entering" constants
+// (i_n, c_n) and B the "leaving" ones (i_f, c_f); for a negative direction it is the other way round. A plane coordinate P gives
+// the parameter fma(P, i, c) ~ (P - o) / d; min / max of the two planes' values are the entering / leaving parameters. The
+// constants are rounded so that every error makes the overlap LONGER (the walk may only err towards testing more candidates):
 //     i0  = rcp((float)d)                        relative error < 2^-22.4 (conversion 2^-24, v_rcp_f32 one ulp)
 //     i_n = i0 (1 - 2^-21),  i_f = i0 (1 + 2^-21)    so |i_n| < |1 / d| < |i_f| by at least 2^-23 relative, whatever i0's error
 //     c_n = fl(-o i_n) - margin,  c_f = fl(-o i_f) + margin   (the product in f64 from the f64 origin; margin = 2^-22 relative
@@ -942,17 +949,15 @@ PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, cons
 // Entering: fma(P, i_n, c_n) = (P - o) i_n - m before its one rounding; for a positive parameter T = (P - o) / d that is at most
 // T (1 - 2^-23), which the fma's rounding (2^-24) cannot lift above T; a negative one stays negative (it is clamped to 0 anyway).
 // Leaving: fma(P, i_f, c_f) >= T (1 + 2^-23) (1 - 2^-24) >= T for T >= 0; a box with T < 0 lies behind the ray and may be rejected.
+// For a box the ray really passes (entering <= leaving, leaving >= 0) the two values come out in that order, so min / max pick
+// them correctly; for any other box a wrong order can only turn a rejection into a visit or keep it a rejection.
 // An axis the ray is parallel to (|i0| > 1e18 or NaN - which also keeps every product below FLT_MAX for |coordinates| <= 1e18) is
-// switched off: (0, -inf) and (0, +inf).
-//
-// When the directions of all the wavefront's rays have the same sign on an axis - nearly always: they pass through one pixel, or
-// leave neighbouring points for one light - the scalar unit picks the entering and the leaving plane pair of the node for that
-// axis and a step is 6 packed fmas + 8 min / max + 3 compares for both children. Otherwise (`mixed`) both planes go through both
-// pairs of constants and min / max sort them out per lane.
+// switched off: A = (0, -inf), B = (0, +inf).
+// A step is 6 packed fmas + 20 min / max + 3 compares for both children.
 // ------------------------------------------------------------------------------------------------
 typedef float pt_f32x2 __attribute__((ext_vector_type(2)));
 struct PtRayPk {
-    pt_f32x2 n[3], f[3];  // per axis (i_n, c_n), (i_f, c_f)
+    pt_f32x2 a[3], b[3];  // per axis (i, c) for the children's lower planes / upper planes
 };
 PT_HD float pt_rcp_f32(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -961,47 +966,27 @@ PT_HD float pt_rcp_f32(float x) {
     return 1.0f / x;
 #endif
 }
-// returns 0: axis switched off, 1: positive direction, 2: negative direction
-PT_HD int pt_raypk_axis(double o, double d, pt_f32x2* n, pt_f32x2* f) {
+PT_HD void pt_raypk_axis(double o, double d, pt_f32x2* a, pt_f32x2* b) {
     const float i0 = pt_rcp_f32((float)d);
     if (!(fabsf(i0) <= 1e18f)) {
-        n->x = 0.0f; n->y = -INFINITY; f->x = 0.0f; f->y = INFINITY;
-        return 0;
+        a->x = 0.0f; a->y = -INFINITY; b->x = 0.0f; b->y = INFINITY;
+        return;
     }
     const float k = 4.76837158203125e-7f;  // 2^-21
     const float in = i0 - i0 * k, fi = i0 + i0 * k;
     float cn = (float)(-(o * (double)in)), cf = (float)(-(o * (double)fi));
     cn = cn - (fabsf(cn) * 2.4e-7f + 1e-37f);
     cf = cf + (fabsf(cf) * 2.4e-7f + 1e-37f);
-    n->x = in; n->y = cn; f->x = fi; f->y = cf;
-    return i0 < 0.0f ? 2 : 1;
+    const bool neg = i0 < 0.0f;  // entering through the upper plane
+    a->x = neg ? fi : in; a->y = neg ? cf : cn;
+    b->x = neg ? in : fi; b->y = neg ? cn : cf;
 }
-// Constants of `r` for this lane; *neg / *pos get bit a set when the lane's direction is negative / positive on axis a.
-PT_HD PtRayPk pt_raypk(const PtRay& r, uint32_t* neg, uint32_t* pos) {
+PT_HD PtRayPk pt_raypk(const PtRay& r) {
     PtRayPk q;
-    const int sx = pt_raypk_axis(r.o.x, r.d.x, &q.n[0], &q.f[0]);
-    const int sy = pt_raypk_axis(r.o.y, r.d.y, &q.n[1], &q.f[1]);
-    const int sz = pt_raypk_axis(r.o.z, r.d.z, &q.n[2], &q.f[2]);
-    *neg = (sx == 2 ? 1u : 0u) | (sy == 2 ? 2u : 0u) | (sz == 2 ? 4u : 0u);
-    *pos = (sx == 1 ? 1u : 0u) | (sy == 1 ? 2u : 0u) | (sz == 1 ? 4u : 0u);
+    pt_raypk_axis(r.o.x, r.d.x, &q.a[0], &q.b[0]);
+    pt_raypk_axis(r.o.y, r.d.y, &q.a[1], &q.b[1]);
+    pt_raypk_axis(r.o.z, r.d.z, &q.a[2], &q.b[2]);
     return q;
-}
-// The wavefront's view of its rays' directions: bit a of `neg`: the rays enter slabs of axis a through the upper plane;
-// `mixed`: some axis has rays of both signs among the lanes of `lanes`, the per-lane form of the test is needed.
-struct PtWaveSigns {
-    uint32_t neg;
-    bool mixed;
-};
-PT_HD PtWaveSigns pt_wave_signs(uint32_t neg, uint32_t pos, bool lane_has_ray) {
-    PtWaveSigns w;
-    w.neg = 0; w.mixed = false;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const bool any_neg = PT_BALLOT(lane_has_ray && ((neg >> a) & 1u)) != 0ull, any_pos = PT_BALLOT(lane_has_ray && ((pos >> a) & 1u)) != 0ull;
-        if (any_neg) w.neg |= 1u << a;
-        if (any_neg && any_pos) w.mixed = true;
-    }
-    return w;
 }
 PT_HD pt_f32x2 pt_pair_f32(uint32_t a, uint32_t b) { pt_f32x2 v; v.x = pt_f32_of(a); v.y = pt_f32_of(b); return v; }
 // packed fma with per-lane constants (i, c) broadcast to both halves: (p.x i + c, p.y i + c)
@@ -1056,39 +1041,68 @@ PT_HD float pt_min3_raw(float a, float b, float c) {
 }
 // Both child boxes of node record `v` (PtBvhNode as 16 dwords in scalar registers) against every lane's ray over [0, tm].
 // Out: masks of the lanes whose rays reach child 0 / child 1, and of those that reach child 1 strictly before child 0.
-PT_HD void pt_slab_pk2(const pt_u32x16& v, const PtRayPk& q, const PtWaveSigns& ws, float tm, unsigned long long* m0, unsigned long long* m1,
-                       unsigned long long* one_first) {
-    float tn0, tn1, tf0, tf1;
-    if (!ws.mixed) {
-        // the entering / leaving plane pairs of the two children, picked per axis by the scalar unit
-        const bool nx = ws.neg & 1u, ny = ws.neg & 2u, nz = ws.neg & 4u;
-        const pt_f32x2 ex = nx ? pt_pair_f32(v[6], v[7]) : pt_pair_f32(v[0], v[1]), lx = nx ? pt_pair_f32(v[0], v[1]) : pt_pair_f32(v[6], v[7]);
-        const pt_f32x2 ey = ny ? pt_pair_f32(v[8], v[9]) : pt_pair_f32(v[2], v[3]), ly = ny ? pt_pair_f32(v[2], v[3]) : pt_pair_f32(v[8], v[9]);
-        const pt_f32x2 ez = nz ? pt_pair_f32(v[10], v[11]) : pt_pair_f32(v[4], v[5]), lz = nz ? pt_pair_f32(v[4], v[5]) : pt_pair_f32(v[10], v[11]);
-        const pt_f32x2 ax = pt_pk_fma_bcast(ex, q.n[0]), ay = pt_pk_fma_bcast(ey, q.n[1]), az = pt_pk_fma_bcast(ez, q.n[2]);
-        const pt_f32x2 bx = pt_pk_fma_bcast(lx, q.f[0]), by = pt_pk_fma_bcast(ly, q.f[1]), bz = pt_pk_fma_bcast(lz, q.f[2]);
-        tn0 = pt_max3_zero_raw(pt_max2_raw(ax.x, ay.x), az.x); tn1 = pt_max3_zero_raw(pt_max2_raw(ax.y, ay.y), az.y);
-        tf0 = pt_min3_raw(pt_min2_raw(bx.x, by.x), bz.x, tm); tf1 = pt_min3_raw(pt_min2_raw(bx.y, by.y), bz.y, tm);
-    } else {
-        // rays of both signs on some axis: each lane takes the smaller of the two planes' entering values and the larger of their
-        // leaving values (one of the two is the true one, computed conservatively; the other can only lengthen the overlap)
-        float tn[2] = {0.0f, 0.0f}, tf[2] = {tm, tm};
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const pt_f32x2 lo = pt_pair_f32(v[2 * a], v[2 * a + 1]), hi = pt_pair_f32(v[6 + 2 * a], v[6 + 2 * a + 1]);
-            const pt_f32x2 el = pt_pk_fma_bcast(lo, q.n[a]), eh = pt_pk_fma_bcast(hi, q.n[a]);
-            const pt_f32x2 ll = pt_pk_fma_bcast(lo, q.f[a]), lh = pt_pk_fma_bcast(hi, q.f[a]);
-            tn[0] = pt_max2_raw(tn[0], pt_min2_raw(el.x, eh.x)); tn[1] = pt_max2_raw(tn[1], pt_min2_raw(el.y, eh.y));
-            tf[0] = pt_min2_raw(tf[0], pt_max2_raw(ll.x, lh.x)); tf[1] = pt_min2_raw(tf[1], pt_max2_raw(ll.y, lh.y));
-        }
-        tn0 = tn[0]; tn1 = tn[1]; tf0 = tf[0]; tf1 = tf[1];
-    }
+PT_HD void pt_slab_pk2(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned long long* m0, unsigned long long* m1, unsigned long long* one_first) {
+    const pt_f32x2 ax = pt_pk_fma_bcast(pt_pair_f32(v[0], v[1]), q.a[0]), ay = pt_pk_fma_bcast(pt_pair_f32(v[2], v[3]), q.a[1]), az = pt_pk_fma_bcast(pt_pair_f32(v[4], v[5]), q.a[2]);
+    const pt_f32x2 bx = pt_pk_fma_bcast(pt_pair_f32(v[6], v[7]), q.b[0]), by = pt_pk_fma_bcast(pt_pair_f32(v[8], v[9]), q.b[1]), bz = pt_pk_fma_bcast(pt_pair_f32(v[10], v[11]), q.b[2]);
+    const float tn0 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x));
+    const float tn1 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y));
+    const float tf0 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.x, bx.x), pt_max2_raw(ay.x, by.x)), pt_max2_raw(az.x, bz.x), tm);
+    const float tf1 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.y, bx.y), pt_max2_raw(ay.y, by.y)), pt_max2_raw(az.y, bz.y), tm);
     *m0 = PT_FCMP_LE(tn0, tf0);
     *m1 = PT_FCMP_LE(tn1, tf1);
     *one_first = PT_FCMP_LT(tn1, tn0);
 }
 // a lane's exclusive range end as the f32 the slab test compares with, rounded up (inf stays inf)
 PT_HD float pt_tmax32(double t) { float tm = (float)t; return tm + fabsf(tm) * 2.4e-7f; }
+
+// The scalar side of a step in one block: which children the wavefront enters (code 0: neither, 1: child 0 only, 2: child 1
+// only, 3: both), which one first (`near`: the one the majority of the lanes that reach a child enter first; with a single
+// child reached that is that child) and which one waits on the stack (`far`, meaningful for code 3).
+// m0 / m1: lanes reaching child 0 / 1; one_first: lanes reaching child 1 before child 0; lanes: the lanes that count.
+PT_HD uint32_t pt_step_decide(unsigned long long* m0_io, unsigned long long* m1_io, unsigned long long one_first, unsigned long long lanes, uint32_t c0, uint32_t c1,
+                              uint32_t* near, uint32_t* far) {
+    unsigned long long m0 = *m0_io, m1 = *m1_io;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_PK_ASM)
+    uint32_t code, h1, n_sf, n_u, nr, fr;
+    unsigned long long t;
+    asm volatile(
+        "s_and_b64 %[m0], %[m0], %[lanes]\n\t"
+        "s_cselect_b32 %[code], 1, 0\n\t"
+        "s_and_b64 %[m1], %[m1], %[lanes]\n\t"
+        "s_cselect_b32 %[h1], 2, 0\n\t"
+        "s_orn2_b64 %[t], %[of], %[m0]\n\t"      // lanes that reach child 1 first: m1 & (one_first | ~m0)
+        "s_and_b64 %[t], %[t], %[m1]\n\t"
+        "s_bcnt1_i32_b64 %[nsf], %[t]\n\t"
+        "s_or_b64 %[t], %[m0], %[m1]\n\t"
+        "s_bcnt1_i32_b64 %[nu], %[t]\n\t"
+        "s_lshl_b32 %[nsf], %[nsf], 1\n\t"
+        "s_cmp_gt_u32 %[nsf], %[nu]\n\t"         // most of them: child 1 first
+        "s_cselect_b32 %[nr], %[c1], %[c0]\n\t"
+        "s_cselect_b32 %[fr], %[c0], %[c1]\n\t"
+        "s_or_b32 %[code], %[code], %[h1]"
+        : [code] "=&s"(code), [h1] "=&s"(h1), [t] "=&s"(t), [nsf] "=&s"(n_sf), [nu] "=&s"(n_u), [nr] "=&s"(nr), [fr] "=&s"(fr), [m0] "+s"(m0), [m1] "+s"(m1)
+        : [of] "s"(one_first), [lanes] "s"(lanes), [c0] "s"(c0), [c1] "s"(c1)
+        : "scc");
+    *near = nr; *far = fr; *m0_io = m0; *m1_io = m1;
+    return code;
+#else
+    m0 &= lanes; m1 &= lanes;
+    const unsigned long long second_first = m1 & (one_first | ~m0);
+    const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
+    *near = swap ? c1 : c0; *far = swap ? c0 : c1; *m0_io = m0; *m1_io = m1;
+    return (m0 ? 1u : 0u) | (m1 ? 2u : 0u);
+#endif
+}
+// node record `index` of the tree array at `base` (64-byte records): one scalar load with a 32-bit byte offset
+PT_HD pt_u32x16 pt_sload_node(const void* base, uint32_t index) {
+    pt_u32x16 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pt_uniform_ptr(base)), "s"(index << 6) : "memory");
+#else
+    v = static_cast<const pt_u32x16*>(base)[index];
+#endif
+    return v;
+}
 
 // One flattened node against every participating lane's ray; `node` is wave-uniform.
 template <bool STATS, bool HIER>
@@ -1140,9 +1154,9 @@ PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRa
     return true;
 }
 
-// wstack: the wavefront's LDS columns (entry k at wstack[(k >> 6) * PT_BLOCK + (k & 63)]), wcap * 64 words in all.
+// wstack: the wavefront's own stack in LDS, `wwords` 32-bit words, linear.
 template <bool STATS, bool HIER>
-PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wcap,
+PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wwords,
                            unsigned int* overflow, PtCounters* cnt) {
     if (has_ray) { best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0; }
     if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return;
@@ -1150,60 +1164,57 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     bool alive = has_ray;               // the lane still wants candidates (a shadow ray stops at its first hit)
     unsigned long long amask = PT_BALLOT(alive);  // the same as a wave-uniform mask: the slab test's results are masks, never per-lane booleans
     unsigned long long in = ~0ull;      // wave-uniform: lanes whose rays reach the current node's box
-    uint32_t neg, pos;
-    const PtRayPk q = pt_raypk(ray, &neg, &pos);
-    const PtWaveSigns ws = pt_wave_signs(neg, pos, has_ray);
+    const PtRayPk q = pt_raypk(ray);
     float tm = INFINITY;                 // best.t as the f32 bound of the slab test, rounded up; follows best.t
     uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
     int sp = 0;                          // words on the stack
     constexpr int W = STATS ? 3 : 1;     // per entry: the node, and in the counting build the mask of the lanes that reach it
-    auto slot = [&](int k) -> uint32_t& { return wstack[(k >> 6) * PT_BLOCK + (k & 63)]; };
-    const int words = wcap * 64 < W * sc.stack_cap ? wcap * 64 : W * sc.stack_cap;  // scene.stack_cap entries, if the LDS columns hold them
-#ifdef PT_PREFETCH_CHILDREN
-    uint32_t pf0 = 0, pf1 = 0;
-#endif
+    const int words = wwords < W * sc.stack_cap ? wwords : W * sc.stack_cap;  // scene.stack_cap entries, if the LDS region holds them
     for (;;) {
+        // Down to the next leaf: ONE loop with one way out (a leaf reference, or PT_REF_EMPTY when nothing is left / the stack
+        // overflowed) - every `return` or `break` in here costs scalar instructions in EVERY step (the compiler turns the
+        // exits into flags it sets and tests), and the scalar unit is what these steps wait for.
+        bool overflowed = false;
         while (!(cur & PT_REF_LEAF)) {
-#ifdef PT_PREFETCH_CHILDREN
-            const pt_u32x16 v = pt_sload16_after(sc.bvh + cur, pf0, pf1);
-            pf0 = pt_sprefetch((v[12] & PT_REF_LEAF) ? (const void*)(sc.inv + 12 * (size_t)((v[12] & ~PT_REF_LEAF) >> 3)) : (const void*)(sc.bvh + v[12]));
-            pf1 = pt_sprefetch((v[13] & PT_REF_LEAF) ? (const void*)(sc.inv + 12 * (size_t)((v[13] & ~PT_REF_LEAF) >> 3)) : (const void*)(sc.bvh + v[13]));
-#else
-            const pt_u32x16 v = pt_sload16(sc.bvh + cur);
-#endif
+            const pt_u32x16 v = pt_sload_node(sc.bvh, cur);
             PT_WAVE_COUNT(4);
             const unsigned long long mine = STATS ? (amask & in) : amask;
             if (STATS && (mine & self)) cnt->n_inner++;
             unsigned long long m0, m1, one_first;
-            pt_slab_pk2(v, q, ws, tm, &m0, &m1, &one_first);
-            m0 &= mine; m1 &= mine;
-            const uint32_t c0 = v[12], c1 = v[13];
-            if (m0 && m1) {
-                const unsigned long long second_first = m1 & (~m0 | one_first);  // lanes that would enter child 1 first
-                const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
-                if (sp + W > words) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                    if (overflow) atomicOr(overflow, 1u);
-#endif
-                    if (STATS) cnt->stack_overflow++;
-                    if (has_ray) best.node = PT_NO_HIT;
-                    return;
+            pt_slab_pk2(v, q, tm, &m0, &m1, &one_first);
+            uint32_t near, far;
+            const uint32_t code = pt_step_decide(&m0, &m1, one_first, mine, v[12], v[13], &near, &far);
+            uint32_t next = near;
+            if (STATS) in = (code == 3u ? near == v[12] : code == 1u) ? m0 : m1;
+            if (code == 3u) {  // both: the other one waits on the stack
+                if (sp + W <= words) {
+                    wstack[sp] = far;
+                    if (STATS) { const unsigned long long far_mask = far == v[12] ? m0 : m1; wstack[sp + 1] = (uint32_t)far_mask; wstack[sp + 2] = (uint32_t)(far_mask >> 32); }
+                    sp += W;
+                } else {
+                    overflowed = true; next = PT_REF_EMPTY;
                 }
-                const unsigned long long far_mask = swap ? m0 : m1;
-                slot(sp) = swap ? c0 : c1;
-                if (STATS) { slot(sp + 1) = (uint32_t)far_mask; slot(sp + 2) = (uint32_t)(far_mask >> 32); }
-                sp += W;
-                cur = swap ? c1 : c0; in = swap ? m1 : m0;
-            } else if (m0) {
-                cur = c0; in = m0;
-            } else if (m1) {
-                cur = c1; in = m1;
-            } else {
-                if (sp == 0) return;
-                sp -= W;
-                cur = PT_UNIFORM_U32(slot(sp));
-                if (STATS) in = (unsigned long long)PT_UNIFORM_U32(slot(sp + 1)) | ((unsigned long long)PT_UNIFORM_U32(slot(sp + 2)) << 32);
             }
+            if (code == 0u) {  // neither: the next pending subtree
+                if (sp > 0) {
+                    sp -= W;
+                    next = PT_UNIFORM_U32(wstack[sp]);
+                    if (STATS) in = (unsigned long long)PT_UNIFORM_U32(wstack[sp + 1]) | ((unsigned long long)PT_UNIFORM_U32(wstack[sp + 2]) << 32);
+                } else {
+                    next = PT_REF_EMPTY;
+                }
+            }
+            cur = next;
+        }
+        if (cur == PT_REF_EMPTY) {
+            if (overflowed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (overflow) atomicOr(overflow, 1u);
+#endif
+                if (STATS) cnt->stack_overflow++;
+                if (has_ray) best.node = PT_NO_HIT;
+            }
+            return;
         }
         const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
         PT_WAVE_COUNT(5);
@@ -1225,8 +1236,8 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
         if (!amask) return;
         if (sp == 0) return;
         sp -= W;
-        cur = PT_UNIFORM_U32(slot(sp));
-        if (STATS) in = (unsigned long long)PT_UNIFORM_U32(slot(sp + 1)) | ((unsigned long long)PT_UNIFORM_U32(slot(sp + 2)) << 32);
+        cur = PT_UNIFORM_U32(wstack[sp]);
+        if (STATS) in = (unsigned long long)PT_UNIFORM_U32(wstack[sp + 1]) | ((unsigned long long)PT_UNIFORM_U32(wstack[sp + 2]) << 32);
     }
 }
 
@@ -1239,7 +1250,7 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
 // range bookkeeping (pt_kdmesh_hit) on `lane_stk`, a per-lane stack beside the wavefront's. HIER: the hierarchical semantics
 // (every SceneNode's own inverse on the way down, ties by depth-first rank).
 template <bool STATS, bool KDMESH, bool HIER, class LaneStack>
-PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wcap,
+PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wwords,
                                 const LaneStack& lane_stk, unsigned int* overflow, PtCounters* cnt) {
     if (has_ray) { best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0; }
     if (sc.n_nodes == 0 || sc.tlas_root == PT_REF_EMPTY) return;
@@ -1247,15 +1258,13 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     bool part = has_ray;      // ... and takes part in the tree being walked (inside a mesh: its ray passed the mesh's box test)
     unsigned long long pmask = PT_BALLOT(alive && part);  // the lanes the slab test's results count for, as a wave-uniform mask
     PtRay local = ray;        // the ray in the space of the tree being walked
-    uint32_t neg, pos;
-    PtRayPk q = pt_raypk(ray, &neg, &pos);
-    PtWaveSigns ws = pt_wave_signs(neg, pos, has_ray);
+    PtRayPk q = pt_raypk(ray);
     float tm = INFINITY;      // best.t as the f32 bound of the slab test (t means the same in every space, ray.rs:130-135)
     uint32_t inst = PT_NO_HIT;  // wave-uniform: flat node of the mesh instance being walked
     uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
     int sp = 0;
-    auto slot = [&](int k) -> uint32_t& { return wstack[(k >> 6) * PT_BLOCK + (k & 63)]; };
-    const int words = wcap * 64 < sc.stack_cap ? wcap * 64 : sc.stack_cap;
+    auto slot = [&](int k) -> uint32_t& { return wstack[k]; };
+    const int words = wwords < sc.stack_cap ? wwords : sc.stack_cap;
     auto overflowed = [&]() {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (overflow) atomicOr(overflow, 1u);
@@ -1264,30 +1273,26 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
         if (has_ray) best.node = PT_NO_HIT;
     };
     for (;;) {
-        bool popped = false;
+        // down to the next leaf: one loop, one way out (see pt_trace_packet) - a leaf reference, PT_REF_POP when neither child is
+        // reached, PT_REF_EMPTY when the stack overflowed
         while (!(cur & PT_REF_LEAF)) {
-            const pt_u32x16 v = pt_sload16(sc.bvh + cur);
+            const pt_u32x16 v = pt_sload_node(sc.bvh, cur);
             PT_WAVE_COUNT(4);
             if (STATS && alive && part) cnt->n_inner++;
             unsigned long long m0, m1, one_first;
-            pt_slab_pk2(v, q, ws, tm, &m0, &m1, &one_first);
-            m0 &= pmask; m1 &= pmask;
-            const uint32_t c0 = v[12], c1 = v[13];
-            if (m0 && m1) {
-                const unsigned long long second_first = m1 & (~m0 | one_first);
-                const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
-                if (sp + 1 > words) { overflowed(); return; }
-                slot(sp) = swap ? c0 : c1; sp++;
-                cur = swap ? c1 : c0;
-            } else if (m0) {
-                cur = c0;
-            } else if (m1) {
-                cur = c1;
-            } else {
-                popped = true;
-                break;
+            pt_slab_pk2(v, q, tm, &m0, &m1, &one_first);
+            uint32_t near, far;
+            const uint32_t code = pt_step_decide(&m0, &m1, one_first, pmask, v[12], v[13], &near, &far);
+            uint32_t next = near;
+            if (code == 3u) {
+                if (sp + 1 <= words) { slot(sp) = far; sp++; }
+                else next = PT_REF_EMPTY;
             }
+            if (code == 0u) next = PT_REF_POP;
+            cur = next;
         }
+        if (cur == PT_REF_EMPTY) { overflowed(); return; }
+        const bool popped = cur == PT_REF_POP;
         if (!popped) {
             const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
             PT_WAVE_COUNT(5);
@@ -1364,8 +1369,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         if (i + 1 < count) { slot(sp) = PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2); sp++; }  // the rest of this leaf
                         slot(sp) = PT_REF_MARKER; sp++;
                         local = lr; part = inside; inst = node;
-                        q = pt_raypk(lr, &neg, &pos);
-                        ws = pt_wave_signs(neg, pos, inside);
+                        q = pt_raypk(lr);
                         cur = root;
                         entered = true;
                     } else if (alive) {
@@ -1387,8 +1391,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
             cur = PT_UNIFORM_U32(slot(sp));
             if (cur != PT_REF_MARKER) break;
             inst = PT_NO_HIT; local = ray; part = has_ray;
-            q = pt_raypk(ray, &neg, &pos);
-            ws = pt_wave_signs(neg, pos, alive);
+            q = pt_raypk(ray);
             pmask = PT_BALLOT(alive && part);
         }
     }
