@@ -966,11 +966,12 @@ PT_HD float pt_rcp_f32(float x) {
     return 1.0f / x;
 #endif
 }
-PT_HD void pt_raypk_axis(double o, double d, pt_f32x2* a, pt_f32x2* b) {
+// returns 0: axis switched off, 1: positive direction, 2: negative direction
+PT_HD int pt_raypk_axis(double o, double d, pt_f32x2* a, pt_f32x2* b) {
     const float i0 = pt_rcp_f32((float)d);
     if (!(fabsf(i0) <= 1e18f)) {
         a->x = 0.0f; a->y = -INFINITY; b->x = 0.0f; b->y = INFINITY;
-        return;
+        return 0;
     }
     const float k = 4.76837158203125e-7f;  // 2^-21
     const float in = i0 - i0 * k, fi = i0 + i0 * k;
@@ -980,12 +981,29 @@ PT_HD void pt_raypk_axis(double o, double d, pt_f32x2* a, pt_f32x2* b) {
     const bool neg = i0 < 0.0f;  // entering through the upper plane
     a->x = neg ? fi : in; a->y = neg ? cf : cn;
     b->x = neg ? in : fi; b->y = neg ? cn : cf;
+    return neg ? 2 : 1;
 }
-PT_HD PtRayPk pt_raypk(const PtRay& r) {
+// Constants of `r` for this lane. *oct (wave-uniform): how the directions of the rays of the lanes in `lanes` relate to the axes -
+// bit a set: they all enter slabs of axis a through the UPPER plane (negative direction), clear: through the lower one; PT_OCT_MIXED
+// when some axis has rays of both signs among those lanes. Rays through one pixel, or from neighbouring points to one light,
+// nearly always share their signs, and then the tree step needs no min / max to tell entering from leaving (pt_slab_pk2).
+#define PT_OCT_MIXED 8
+PT_HD PtRayPk pt_raypk(const PtRay& r) {  // without the wavefront's view: for walks that always take the per-lane form
     PtRayPk q;
     pt_raypk_axis(r.o.x, r.d.x, &q.a[0], &q.b[0]);
     pt_raypk_axis(r.o.y, r.d.y, &q.a[1], &q.b[1]);
     pt_raypk_axis(r.o.z, r.d.z, &q.a[2], &q.b[2]);
+    return q;
+}
+PT_HD PtRayPk pt_raypk(const PtRay& r, bool lanes, int* oct) {
+    PtRayPk q;
+    const int sx = pt_raypk_axis(r.o.x, r.d.x, &q.a[0], &q.b[0]);
+    const int sy = pt_raypk_axis(r.o.y, r.d.y, &q.a[1], &q.b[1]);
+    const int sz = pt_raypk_axis(r.o.z, r.d.z, &q.a[2], &q.b[2]);
+    const bool nx = PT_BALLOT(lanes && sx == 2) != 0ull, px = PT_BALLOT(lanes && sx == 1) != 0ull;
+    const bool ny = PT_BALLOT(lanes && sy == 2) != 0ull, py = PT_BALLOT(lanes && sy == 1) != 0ull;
+    const bool nz = PT_BALLOT(lanes && sz == 2) != 0ull, pz = PT_BALLOT(lanes && sz == 1) != 0ull;
+    *oct = ((nx && px) || (ny && py) || (nz && pz)) ? PT_OCT_MIXED : ((nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0));
     return q;
 }
 PT_HD pt_f32x2 pt_pair_f32(uint32_t a, uint32_t b) { pt_f32x2 v; v.x = pt_f32_of(a); v.y = pt_f32_of(b); return v; }
@@ -1041,13 +1059,25 @@ PT_HD float pt_min3_raw(float a, float b, float c) {
 }
 // Both child boxes of node record `v` (PtBvhNode as 16 dwords in scalar registers) against every lane's ray over [0, tm].
 // Out: masks of the lanes whose rays reach child 0 / child 1, and of those that reach child 1 strictly before child 0.
+// OCT (see pt_raypk): with wave-uniform signs the entering value of an axis is the lower planes' (bit clear) or the upper planes'
+// (bit set) - known at compile time, 6 packed fmas + 8 min / max + 3 compares; PT_OCT_MIXED: min / max of the two per lane (+ 12).
+template <int OCT>
 PT_HD void pt_slab_pk2(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned long long* m0, unsigned long long* m1, unsigned long long* one_first) {
     const pt_f32x2 ax = pt_pk_fma_bcast(pt_pair_f32(v[0], v[1]), q.a[0]), ay = pt_pk_fma_bcast(pt_pair_f32(v[2], v[3]), q.a[1]), az = pt_pk_fma_bcast(pt_pair_f32(v[4], v[5]), q.a[2]);
     const pt_f32x2 bx = pt_pk_fma_bcast(pt_pair_f32(v[6], v[7]), q.b[0]), by = pt_pk_fma_bcast(pt_pair_f32(v[8], v[9]), q.b[1]), bz = pt_pk_fma_bcast(pt_pair_f32(v[10], v[11]), q.b[2]);
-    const float tn0 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x));
-    const float tn1 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y));
-    const float tf0 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.x, bx.x), pt_max2_raw(ay.x, by.x)), pt_max2_raw(az.x, bz.x), tm);
-    const float tf1 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.y, bx.y), pt_max2_raw(ay.y, by.y)), pt_max2_raw(az.y, bz.y), tm);
+    float tn0, tn1, tf0, tf1;
+    if (OCT == PT_OCT_MIXED) {
+        tn0 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x));
+        tn1 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y));
+        tf0 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.x, bx.x), pt_max2_raw(ay.x, by.x)), pt_max2_raw(az.x, bz.x), tm);
+        tf1 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.y, bx.y), pt_max2_raw(ay.y, by.y)), pt_max2_raw(az.y, bz.y), tm);
+    } else {
+        const pt_f32x2 ex = (OCT & 1) ? bx : ax, lx = (OCT & 1) ? ax : bx;  // entering / leaving values per axis, both children
+        const pt_f32x2 ey = (OCT & 2) ? by : ay, ly = (OCT & 2) ? ay : by;
+        const pt_f32x2 ez = (OCT & 4) ? bz : az, lz = (OCT & 4) ? az : bz;
+        tn0 = pt_max3_zero_raw(pt_max2_raw(ex.x, ey.x), ez.x); tn1 = pt_max3_zero_raw(pt_max2_raw(ex.y, ey.y), ez.y);
+        tf0 = pt_min3_raw(pt_min2_raw(lx.x, ly.x), lz.x, tm); tf1 = pt_min3_raw(pt_min2_raw(lx.y, ly.y), lz.y, tm);
+    }
     *m0 = PT_FCMP_LE(tn0, tf0);
     *m1 = PT_FCMP_LE(tn1, tf1);
     *one_first = PT_FCMP_LT(tn1, tn0);
@@ -1154,6 +1184,71 @@ PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRa
     return true;
 }
 
+// Down from inner node `cur` to the next leaf: ONE loop with one way out - `cur` becomes a leaf reference, or PT_REF_EMPTY when
+// nothing is left (or the stack overflowed: `overflowed`). Every `return` or `break` in here would cost scalar instructions in
+// EVERY step (the compiler turns the exits into flags it sets and tests), and the CU's one scalar unit is what these steps wait
+// for. `lanes`: the lanes whose rays count; W words per stack entry (3 in the counting build: the node and the mask of the lanes
+// that reach it, which `in` follows).
+template <bool STATS, int OCT>
+PT_HD void pt_descend(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned long long lanes, unsigned long long self, uint32_t& cur, int& sp, unsigned long long& in,
+                      bool& overflowed, uint32_t* wstack, int words, PtCounters* cnt) {
+    constexpr int W = STATS ? 3 : 1;
+    while (!(cur & PT_REF_LEAF)) {
+        const pt_u32x16 v = pt_sload_node(bvh, cur);
+        PT_WAVE_COUNT(4);
+        const unsigned long long mine = STATS ? (lanes & in) : lanes;
+        if (STATS && (mine & self)) cnt->n_inner++;
+        unsigned long long m0, m1, one_first;
+        pt_slab_pk2<OCT>(v, q, tm, &m0, &m1, &one_first);
+        uint32_t near, far;
+        const uint32_t code = pt_step_decide(&m0, &m1, one_first, mine, v[12], v[13], &near, &far);
+        uint32_t next = near;
+        if (STATS) in = (code == 3u ? near == v[12] : code == 1u) ? m0 : m1;
+        if (code == 3u) {  // both: the other one waits on the stack
+            if (sp + W <= words) {
+                wstack[sp] = far;
+                if (STATS) { const unsigned long long far_mask = far == v[12] ? m0 : m1; wstack[sp + 1] = (uint32_t)far_mask; wstack[sp + 2] = (uint32_t)(far_mask >> 32); }
+                sp += W;
+            } else {
+                overflowed = true; next = PT_REF_EMPTY;
+            }
+        }
+        if (code == 0u) {  // neither: the next pending subtree
+            if (sp > 0) {
+                sp -= W;
+                next = PT_UNIFORM_U32(wstack[sp]);
+                if (STATS) in = (unsigned long long)PT_UNIFORM_U32(wstack[sp + 1]) | ((unsigned long long)PT_UNIFORM_U32(wstack[sp + 2]) << 32);
+            } else {
+                next = PT_REF_EMPTY;
+            }
+        }
+        cur = next;
+    }
+}
+
+// The same inside the two-level walk of scenes with mesh instances: PT_REF_POP when neither child is reached (the caller pops: a
+// marker may end a mesh instance), PT_REF_EMPTY when the stack overflowed.
+template <bool STATS, int OCT>
+PT_HD void pt_descend_mesh(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned long long lanes, bool counts, uint32_t& cur, int& sp, uint32_t* wstack, int words,
+                           PtCounters* cnt) {
+    while (!(cur & PT_REF_LEAF)) {
+        const pt_u32x16 v = pt_sload_node(bvh, cur);
+        PT_WAVE_COUNT(4);
+        if (STATS && counts) cnt->n_inner++;
+        unsigned long long m0, m1, one_first;
+        pt_slab_pk2<OCT>(v, q, tm, &m0, &m1, &one_first);
+        uint32_t near, far;
+        const uint32_t code = pt_step_decide(&m0, &m1, one_first, lanes, v[12], v[13], &near, &far);
+        uint32_t next = near;
+        if (code == 3u) {
+            if (sp + 1 <= words) { wstack[sp] = far; sp++; }
+            else next = PT_REF_EMPTY;
+        }
+        if (code == 0u) next = PT_REF_POP;
+        cur = next;
+    }
+}
+
 // wstack: the wavefront's own stack in LDS, `wwords` 32-bit words, linear.
 template <bool STATS, bool HIER>
 PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wwords,
@@ -1164,47 +1259,28 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     bool alive = has_ray;               // the lane still wants candidates (a shadow ray stops at its first hit)
     unsigned long long amask = PT_BALLOT(alive);  // the same as a wave-uniform mask: the slab test's results are masks, never per-lane booleans
     unsigned long long in = ~0ull;      // wave-uniform: lanes whose rays reach the current node's box
-    const PtRayPk q = pt_raypk(ray);
+    int oct;
+    const PtRayPk q = pt_raypk(ray, has_ray, &oct);
     float tm = INFINITY;                 // best.t as the f32 bound of the slab test, rounded up; follows best.t
     uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
     int sp = 0;                          // words on the stack
     constexpr int W = STATS ? 3 : 1;     // per entry: the node, and in the counting build the mask of the lanes that reach it
     const int words = wwords < W * sc.stack_cap ? wwords : W * sc.stack_cap;  // scene.stack_cap entries, if the LDS region holds them
     for (;;) {
-        // Down to the next leaf: ONE loop with one way out (a leaf reference, or PT_REF_EMPTY when nothing is left / the stack
-        // overflowed) - every `return` or `break` in here costs scalar instructions in EVERY step (the compiler turns the
-        // exits into flags it sets and tests), and the scalar unit is what these steps wait for.
         bool overflowed = false;
-        while (!(cur & PT_REF_LEAF)) {
-            const pt_u32x16 v = pt_sload_node(sc.bvh, cur);
-            PT_WAVE_COUNT(4);
-            const unsigned long long mine = STATS ? (amask & in) : amask;
-            if (STATS && (mine & self)) cnt->n_inner++;
-            unsigned long long m0, m1, one_first;
-            pt_slab_pk2(v, q, tm, &m0, &m1, &one_first);
-            uint32_t near, far;
-            const uint32_t code = pt_step_decide(&m0, &m1, one_first, mine, v[12], v[13], &near, &far);
-            uint32_t next = near;
-            if (STATS) in = (code == 3u ? near == v[12] : code == 1u) ? m0 : m1;
-            if (code == 3u) {  // both: the other one waits on the stack
-                if (sp + W <= words) {
-                    wstack[sp] = far;
-                    if (STATS) { const unsigned long long far_mask = far == v[12] ? m0 : m1; wstack[sp + 1] = (uint32_t)far_mask; wstack[sp + 2] = (uint32_t)(far_mask >> 32); }
-                    sp += W;
-                } else {
-                    overflowed = true; next = PT_REF_EMPTY;
-                }
+        if (!(cur & PT_REF_LEAF)) {
+            const unsigned long long mine = amask;
+            switch (STATS ? PT_OCT_MIXED : oct) {  // the counting build always takes the per-lane form (its images are compared with the plain build's)
+            case 0: pt_descend<STATS, 0>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            case 1: pt_descend<STATS, 1>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            case 2: pt_descend<STATS, 2>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            case 3: pt_descend<STATS, 3>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            case 4: pt_descend<STATS, 4>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            case 5: pt_descend<STATS, 5>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            case 6: pt_descend<STATS, 6>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            case 7: pt_descend<STATS, 7>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            default: pt_descend<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
             }
-            if (code == 0u) {  // neither: the next pending subtree
-                if (sp > 0) {
-                    sp -= W;
-                    next = PT_UNIFORM_U32(wstack[sp]);
-                    if (STATS) in = (unsigned long long)PT_UNIFORM_U32(wstack[sp + 1]) | ((unsigned long long)PT_UNIFORM_U32(wstack[sp + 2]) << 32);
-                } else {
-                    next = PT_REF_EMPTY;
-                }
-            }
-            cur = next;
         }
         if (cur == PT_REF_EMPTY) {
             if (overflowed) {
@@ -1273,24 +1349,11 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
         if (has_ray) best.node = PT_NO_HIT;
     };
     for (;;) {
-        // down to the next leaf: one loop, one way out (see pt_trace_packet) - a leaf reference, PT_REF_POP when neither child is
-        // reached, PT_REF_EMPTY when the stack overflowed
-        while (!(cur & PT_REF_LEAF)) {
-            const pt_u32x16 v = pt_sload_node(sc.bvh, cur);
-            PT_WAVE_COUNT(4);
-            if (STATS && alive && part) cnt->n_inner++;
-            unsigned long long m0, m1, one_first;
-            pt_slab_pk2(v, q, tm, &m0, &m1, &one_first);
-            uint32_t near, far;
-            const uint32_t code = pt_step_decide(&m0, &m1, one_first, pmask, v[12], v[13], &near, &far);
-            uint32_t next = near;
-            if (code == 3u) {
-                if (sp + 1 <= words) { slot(sp) = far; sp++; }
-                else next = PT_REF_EMPTY;
-            }
-            if (code == 0u) next = PT_REF_POP;
-            cur = next;
-        }
+        // down to the next leaf (pt_descend_mesh): a leaf reference, PT_REF_POP when neither child is reached, PT_REF_EMPTY when the
+        // stack overflowed. Always the per-lane form of the slab test: the walks of these scenes are short (5.7 tree steps per ray on
+        // macho-cows, 8.6 on the mirror scene) and the octant bookkeeping per ray and per mesh instance cost more than the eight
+        // instructions per step it saves (cows -6 %, mirror -3 %; big-scene, mesh-free, +4 %: profiles/r03/notes.md).
+        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt);
         if (cur == PT_REF_EMPTY) { overflowed(); return; }
         const bool popped = cur == PT_REF_POP;
         if (!popped) {
