@@ -105,13 +105,13 @@ def measured_profile(key, kernel):
 
 
 def needed_hbm_bytes(scene_export, pixels, n_chunks):
-    """What one frame has to move through HBM if nothing is read twice: the scene once (node records, triangles, trees), one
-    background colour per pixel, one 24-byte chunk sum per (pixel, 8-sample chunk), written by the render kernel and read by
-    the finishing pass, 3 bytes per pixel out."""
+    """What one launch of the render kernel has to move through HBM if nothing is read twice: the scene once (node records,
+    triangles, trees), at most one background colour per pixel, and one 24-byte chunk sum per (pixel, 8-sample chunk) written
+    (the finishing pass, a kernel of its own, reads them and writes the 3 bytes per pixel)."""
     n = int(len(scene_export["prim_type"]))
     tris = int(scene_export["mesh_tri_off"][-1]) + int(scene_export["n_triangles"])
     scene = n * ((12 + 12 + 9) * 8 + 16) + tris * 72 + (2 * n + tris) * 64
-    return scene + pixels * (24 + 3) + 2 * 24 * pixels * n_chunks
+    return scene + pixels * 24 + 24 * pixels * n_chunks
 
 
 def roofline_block(key, at_config_size, st, algorithmic, kernel_s, copy_gbps, counts, total, rays_frame, n_lights, traversal, needed_bytes):

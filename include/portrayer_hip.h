@@ -190,7 +190,8 @@ enum { PT_KERNEL_MODE_FLAT = 1, PT_KERNEL_MODE_KD = 2, PT_KERNEL_MODE_FLAT_NOMES
 /* pt_stats.kernel_variant: bit 0-3 waves per SIMD the kernel was compiled for (3 or 4); PT_KERNEL_INTERPRETER: the per-lane
  * interpreter that scenes with reflective materials need (material.rs:216-303), else the straight-line kernel; PT_KERNEL_PARK:
  * a parked recursion frame per lane in LDS; PT_KERNEL_COUNTING: the counting build (collect_stats); PT_KERNEL_TEXTURED */
-enum { PT_KERNEL_WAVES_MASK = 15, PT_KERNEL_INTERPRETER = 16, PT_KERNEL_PARK = 32, PT_KERNEL_COUNTING = 64, PT_KERNEL_TEXTURED = 128 };
+enum { PT_KERNEL_WAVES_MASK = 15, PT_KERNEL_INTERPRETER = 16, PT_KERNEL_PARK = 32, PT_KERNEL_COUNTING = 64, PT_KERNEL_TEXTURED = 128,
+       PT_KERNEL_FORK = 256 /* idle lanes take the refracted subtrees busy lanes offer (LDS queue, ballot / popcount ranks) */ };
 
 int pt_abi_version(void);
 int pt_device_count(void);

@@ -181,6 +181,8 @@ struct pt_context {
     PtBuf spill, stack_spill, accum, bg, rgb, linear, misc;  // misc: work counter + overflow flag (8 B), PtCounters at +256
     bool needs_spill = false;  // some material is reflective (recursion frames) or the scene has more than 32 lights
     bool spawns = false;       // some material is reflective: hits spawn rays, so the cost of a pixel varies by orders of magnitude
+    bool forkable = false;     // ... and no hit draws random numbers after the jitter (no area light, no glossy material): refracted subtrees may be walked by other lanes
+    uint32_t launch_seq = 0;   // PtRenderArgs::launch_nonce
     bool four_waves = false;   // traversal-heavy scene without reflective materials, flat_scene / hierarchical semantics: the 4-waves-per-SIMD kernel
     PtSceneView view;
     bool have_scene = false;
@@ -666,6 +668,19 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         c->four_waves = !c->spawns && ((traverse == PT_TRAVERSE_FLAT && (n >= 256 || instanced_tris >= 65536)) || (traverse == PT_TRAVERSE_HIER && instanced_tris >= 65536));
     }
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
+    {   // fork / join of refracted subtrees (pt_shade.h) needs a recursion that draws no random numbers and a dielectric material to be of use
+        bool draws = false, dielectric = false;
+        for (uint32_t m = 0; m < s->n_materials; m++) {
+            if (mats[10 * (size_t)m + 7] > 0.0 && mats[10 * (size_t)m + 8] > 0.0) draws = true;   // glossy reflection (material.rs:221-239)
+            if (mats[10 * (size_t)m + 7] > 0.0 && mats[10 * (size_t)m + 9] > 0.0) dielectric = true;
+        }
+        for (uint32_t l = 0; l < s->n_lights; l++) {
+            const double* L = &lights[15 * (size_t)l];
+            const bool empty = (L[9] == 0.0 && L[10] == 0.0 && L[11] == 0.0) || (L[12] == 0.0 && L[13] == 0.0 && L[14] == 0.0);  // light.rs:51-53
+            if (!empty) draws = true;
+        }
+        c->forkable = c->spawns && dielectric && !draws && s->n_lights <= PT_LIGHT_ROUND;
+    }
     if ((rc = pt_upload(c, c->materials, mats)) || (rc = pt_upload(c, c->lights, lights))) return rc;
 
     // ---- textures / normal maps (texture.rs)
@@ -903,7 +918,11 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.four_waves = (!c->spawns && c->four_waves) ? 1 : 0;
     if (const char* e = getenv("PORTRAYER_WAVES")) a.four_waves = (!c->spawns && atoi(e) == 4) ? 1 : 0;
     if (kd_sem) a.four_waves = 0;
-    if (c->spawns) a.run_variant = a.park_slots ? PT_RUN_INTERP_PARK : PT_RUN_INTERP;
+    bool fork = c->forkable && a.park_slots;
+    if (const char* e = getenv("PORTRAYER_FORK")) fork = fork && atoi(e) > 0;  // 0: every subtree by the lane that spawned it (tests, measurements)
+    if (c->launch_seq == 0) c->launch_seq = (uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u;  // a different starting point in every context
+    a.launch_nonce = ++c->launch_seq;
+    if (c->spawns) a.run_variant = a.park_slots ? (fork ? PT_RUN_INTERP_FORK : PT_RUN_INTERP_PARK) : PT_RUN_INTERP;
     else if (pt_interpreter_forced()) a.run_variant = a.four_waves ? PT_RUN_INTERP4 : PT_RUN_INTERP;
     else a.run_variant = a.four_waves ? PT_RUN_LINE4 : PT_RUN_LINE3;
     size_t block_budget = a.four_waves ? 39 * 1024 : 52 * 1024;  // 3 x 52 KB or 4 x 39 KB of the CU's 160 KB
@@ -952,7 +971,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.work_queues = (unsigned int*)((char*)c->misc.p + 256 + sizeof(PtCounters));
     c->last_mode = (uint32_t)a.scene.mode;
     c->last_variant = (a.four_waves ? 4u : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4) ? 0u : PT_KERNEL_INTERPRETER) |
-                      (a.run_variant == PT_RUN_INTERP_PARK ? PT_KERNEL_PARK : 0u) | (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
+                      ((a.run_variant == PT_RUN_INTERP_PARK || a.run_variant == PT_RUN_INTERP_FORK) ? PT_KERNEL_PARK : 0u) | (a.run_variant == PT_RUN_INTERP_FORK ? PT_KERNEL_FORK : 0u) | (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));
     if (a.n_items) {
@@ -986,6 +1005,7 @@ static int pt_collect_stats(pt_context* c, pt_stats* st, bool counted) {
         if (head[1] && !st->stack_overflow) st->stack_overflow = 1;
         st->kernel_mode = c->last_mode; st->kernel_variant = c->last_variant;
     }
+    if (head[1] & 2u) return pt_fail(c, PT_ERR_TRAVERSAL, "fork / join of refracted subtrees stalled (a lane waited for a colour nobody was computing): results invalid");
     if (head[1]) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
     return PT_OK;
 }

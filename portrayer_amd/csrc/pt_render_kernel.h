@@ -36,7 +36,10 @@
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 0  // experiments: -DPT_MIN_WAVES=2 / 3 / 4 for every instantiation
 #endif
-#define PT_VAR_WAVES(VAR) (PT_MIN_WAVES ? PT_MIN_WAVES : ((VAR) == 2 ? 4 : 3))
+#ifndef PT_INTERP_WAVES
+#define PT_INTERP_WAVES 3  // experiments: -DPT_INTERP_WAVES=2 compiles the interpreter kernels (VAR 0, 1, 3) for 2 waves per SIMD (256 VGPRs)
+#endif
+#define PT_VAR_WAVES(VAR) (PT_MIN_WAVES ? PT_MIN_WAVES : ((VAR) == 2 ? 4 : PT_INTERP_WAVES))  // VAR 3 = VAR 1 + fork / join of refracted subtrees
 
 __device__ __forceinline__ void pt_flush_counters(PtCounters* dst, const PtCounters& c) {
     const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&c);
@@ -54,7 +57,8 @@ __host__ __device__ inline size_t pt_render_lds_bytes(int stack_lds_cap, bool te
 
 template <int MODE, bool STATS, bool TEX, int VAR>
 __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(PtRenderArgs a) {
-    constexpr int PARK = VAR == 1 ? 1 : 0;
+    constexpr int PARK = (VAR == 1 || VAR == 3) ? 1 : 0;
+    constexpr bool FORK = VAR == 3;  // idle lanes take the refracted subtrees busy lanes offer (pt_shade.h: fork / join)
     extern __shared__ uint32_t pt_lds[];
     const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
@@ -77,6 +81,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
     L.stage = PT_ST_DONE; L.has_ray = false; L.ray_any = false;
     L.item = 0; L.x = L.y = 0; L.light = L.draw = L.draw0 = L.occluded = 0; L.depth = 0; L.lo = 0;
     L.ray.o = L.ray.d = pt_v3(0.0, 0.0, 0.0);
+    L.offer = false; L.base = 0; L.owner = 0; L.fork_seq = 0; L.ticket = 0; L.wait_ticket = 0;
     PtHit hit;
     hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
     unsigned q_next = 0, q_end = 0, q_seen = 0;  // this wavefront's private batch of items (wave-uniform); highest item index seen handed out
@@ -134,6 +139,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
             L.stage = mine0 ? PT_ST_NEW_SAMPLE : PT_ST_DONE;
         }
         L.has_ray = false;
+        unsigned idle_passes = 0;  // FORK: passes in a row in which no lane traced anything (all waiting for mailboxes)
         for (;;) {
             const bool active = L.stage != PT_ST_DONE;
             if (!__any(active)) break;
@@ -143,7 +149,52 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 #ifdef PT_CYCLES
             const unsigned long long cyc_a = __builtin_readcyclecounter();
 #endif
-            if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH, PARK>(a, L, hit, fr, &cnt);
+            if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH, PARK, FORK>(a, L, hit, fr, &cnt);
+            if (FORK) {
+                // Offers and takers, matched by rank: the k-th lane that parked a frame with a refracted ray in this pass writes its
+                // thread index to slot k of the wavefront's queue in LDS (the first words of its traversal stack, free between
+                // walks); the k-th idle lane reads it and takes the ray out of that lane's parked frame.
+                const bool offer = active && L.offer;
+                L.offer = false;
+                const bool idle = L.stage == PT_ST_DONE;
+                const unsigned long long offers = __ballot(offer), idles = __ballot(idle);
+                if (offers && idles) {  // wave-uniform
+                    const int n_off = __builtin_popcountll(offers), n_idle = __builtin_popcountll(idles);
+                    const int n = n_off < n_idle ? n_off : n_idle;
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    uint32_t* queue = pt_fork_queue<MODE>(a, pt_lds);
+                    const int q = __builtin_popcountll(offers & below), r = __builtin_popcountll(idles & below);
+                    const bool given = offer && q < n, takes = idle && r < n;
+                    if (given) queue[q] = threadIdx.x;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const uint32_t owner_tid = takes ? queue[r] : threadIdx.x;
+                    // the owner's pixel and the depth of its frame (its L.depth is already that of the reflected ray: frame = depth - 1)
+                    const uint32_t ox = (uint32_t)__shfl((int)L.x, (int)(owner_tid & 63u)), oy = (uint32_t)__shfl((int)L.y, (int)(owner_tid & 63u));
+                    const int od = __shfl(L.depth, (int)(owner_tid & 63u)) - 1;
+                    if (takes) {
+                        const double* of = fr.park + ((ptrdiff_t)owner_tid - (ptrdiff_t)threadIdx.x);  // the owner's parked frame (LDS column)
+                        uint32_t omat, ofs;
+                        PtFrameRef::unpack_tag(of[PT_H_TAG * PT_FRAME_STRIDE], &omat, &ofs);
+                        L.ray.o = pt_v3(of[(PT_H_P + 0) * PT_FRAME_STRIDE], of[(PT_H_P + 1) * PT_FRAME_STRIDE], of[(PT_H_P + 2) * PT_FRAME_STRIDE]);
+                        L.ray.d = pt_v3(of[(PT_H_DIR + 0) * PT_FRAME_STRIDE], of[(PT_H_DIR + 1) * PT_FRAME_STRIDE], of[(PT_H_DIR + 2) * PT_FRAME_STRIDE]);
+                        L.x = ox; L.y = oy;
+                        L.depth = od + 1; L.base = od + 1; L.lo = od + 1;
+                        L.owner = owner_tid | ((uint32_t)od << 16);
+                        L.ticket = pt_fork_ticket(a.launch_nonce, ofs >> PT_FS_SEQ_SHIFT, od);
+                        L.draw = 2;
+                        L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
+                        if (STATS) { cnt.refract++; cnt.diag[6]++; }
+                    }
+                    __builtin_amdgcn_wave_barrier();  // the owners' frames were read before any of them is marked
+                    if (given) {
+                        uint32_t mat, fs;
+                        PtFrameRef::unpack_tag(fr.p(0, PT_H_TAG), &mat, &fs);
+                        fr.p(0, PT_H_TAG) = PtFrameRef::pack_tag(mat, fs | PT_FS_FORKED);
+                    }
+                }
+            }
 #ifdef PT_CYCLES
             const unsigned long long cyc_b = __builtin_readcyclecounter();
 #endif
@@ -157,16 +208,28 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 #endif
             // One walk per wavefront (pt_trace_wave: pt_trace_packet / pt_trace_packet_mesh, every lane calls it) in the flat_scene and
             // hierarchical semantics; the k-d tree semantics keep the per-lane walk (per-ray ranges and order).
-            if (__any(tracing)) pt_trace_wave<MODE, STATS>(a, L.ray, tracing, L.ray_any, hit, stk, pt_lds, &cnt);
+            if (__any(tracing)) { pt_trace_wave<MODE, STATS>(a, L.ray, tracing, L.ray_any, hit, stk, pt_lds, &cnt); idle_passes = 0; }
+            else if (FORK && ++idle_passes > (1u << 16)) {
+                // Every lane that is not finished waits for a colour no lane is working on: a defect of the fork / join bookkeeping.
+                // Reported like a traversal failure (the render returns PT_ERR_TRAVERSAL) rather than hanging the GPU.
+                if (lane == 0) atomicOr(a.overflow_flag, 2u);
+                L.stage = PT_ST_DONE;
+            }
 #ifdef PT_CYCLES
             if (STATS && lane == 0) cnt.diag[2] += cyc_b - cyc_a;  // the walk's cycles are counted inside pt_trace_wave
 #endif
         }
         // render.rs:36-43 under the summation contract: the chunk's samples in ascending order. A pixel's samples sit
         // in neighbouring lanes; their colours are in the lanes' LDS columns (same wavefront: program order suffices).
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (FORK) {  // the samples' colours went through HBM: make the lanes' stores visible to the lane that adds them up
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         // The lane's place in the item is worked out again (a dozen integer operations on the wave-uniform item index) rather
         // than kept across the loop above, where it would be four registers spilled to scratch memory by every wavefront for
         // every item - 2 GB of HBM writes per frame. The empty asm keeps the compiler from reusing the first computation.
@@ -178,10 +241,19 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
         uint32_t x_again, y_again;
         const bool mine = pt_item_lane(a, w_again, lane, &it, &x_again, &y_again);
         if (mine && it.first) {
-            PtVec3 sum = fr.l3(PT_L_VALUE);
-            for (uint32_t k = 1; k < it.count; k++) {
-                const double* o = fr.lds + k;
-                sum = sum + pt_v3(o[(PT_L_VALUE + 0) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 1) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 2) * PT_FRAME_STRIDE]);
+            PtVec3 sum;
+            if (FORK) {  // finished samples wait in the lanes' result slots in HBM (the LDS frames were reused by taken tasks)
+                sum = fr.h3(PT_RESULT_DEPTH, PT_H_MAIL);
+                for (uint32_t k = 1; k < it.count; k++) {
+                    const double* o = fr.spill + (size_t)k * (PT_SPILL_DEPTHS * PT_SPILL_STRIDE) + PT_RESULT_DEPTH * PT_SPILL_STRIDE + PT_H_MAIL;
+                    sum = sum + pt_v3(o[0], o[1], o[2]);
+                }
+            } else {
+                sum = fr.l3(PT_L_VALUE);
+                for (uint32_t k = 1; k < it.count; k++) {
+                    const double* o = fr.lds + k;
+                    sum = sum + pt_v3(o[(PT_L_VALUE + 0) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 1) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 2) * PT_FRAME_STRIDE]);
+                }
             }
             double* o = a.accum + 3 * ((size_t)(it.slot >> 6) * a.n_chunks * 64 + (size_t)it.chunk * 64 + (it.slot & 63u));
             o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
@@ -243,14 +315,16 @@ static hipError_t pt_launch_kernel(Kernel kernel, size_t lds, const PtRenderArgs
 // Which kernel runs (`variant`, chosen in pt_render_common):
 //   PT_RUN_INTERP / PT_RUN_INTERP_PARK   the interpreter kernel (scenes with reflective materials: hits spawn rays), every parked
 //                                        recursion frame in HBM / the youngest in LDS; 3 waves per SIMD
+//   PT_RUN_INTERP_FORK                   PT_RUN_INTERP_PARK + fork / join: idle lanes take the refracted subtrees busy lanes offer (pt_shade.h)
 //   PT_RUN_LINE3 / PT_RUN_LINE4          the straight-line kernel of pt_render_simple.h (hits spawn nothing), 3 / 4 waves per SIMD
 //   PT_RUN_INTERP4                       -DPT_KEEP_INTERP builds only: the interpreter at 4 waves per SIMD on a scene without reflective
 //                                        materials (what round 2 timed), for A/B runs against the straight-line kernel
 template <int MODE, bool STATS, bool TEX>
 static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_mode, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
-    const size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, variant == PT_RUN_INTERP_PARK ? 1 : 0);
+    const size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, (variant == PT_RUN_INTERP_PARK || variant == PT_RUN_INTERP_FORK) ? 1 : 0);
     switch (variant) {
     case PT_RUN_INTERP_PARK: return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 1>, lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_INTERP_FORK: return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 3>, lds, a, n_cu, stream, grid_out, launch);
     case PT_RUN_INTERP: return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
 #ifdef PT_KEEP_INTERP
     case PT_RUN_INTERP4:

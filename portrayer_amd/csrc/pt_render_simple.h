@@ -68,6 +68,23 @@ PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, 
     if (tracing) pt_trace<MODE, STATS>(a.scene, ray, any, hit, stk, cnt);
 }
 
+// The first words of the wavefront's own traversal stack (free between walks): the queue through which offered rays find takers
+// (pt_render_kernel, FORK). At least 64 words: the wavefront's region is stack_lds_cap x 64 words, or `rows` x 64 behind the lanes' rows.
+template <int MODE>
+PT_HD uint32_t* pt_fork_queue(const PtRenderArgs& a, uint32_t* lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t wave = threadIdx.x >> 6;
+#else
+    const uint32_t wave = 0;
+#endif
+    if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
+        const int rows = a.stack_lds_cap >= 16 ? 8 : (a.stack_lds_cap >= 8 ? 3 : (a.stack_lds_cap >= 4 ? 2 : 1));
+        return lds + (size_t)(a.stack_lds_cap - rows) * PT_BLOCK + (size_t)wave * rows * 64;
+    }
+    if (MODE == PT_MODE_KD || MODE == PT_MODE_KD_NOMESH) return lds + (size_t)(a.stack_lds_cap - 1) * PT_BLOCK + (size_t)wave * 64;  // the lanes' last row (per-lane walks: free between them too)
+    return lds + (size_t)wave * a.stack_lds_cap * 64;
+}
+
 template <int MODE, bool STATS, bool TEX, int WAVES>
 __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRenderArgs a) {
     constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH;

@@ -59,6 +59,11 @@
 #define PT_FENCE
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_THREAD_IN_BLOCK() (threadIdx.x)
+#else
+#define PT_THREAD_IN_BLOCK() 0u
+#endif
 #define PT_QUEUE_STRIDE 32  // words between two queue counters: one 128-byte line each
 #define PT_FINE_QUEUES 64
 #ifndef PT_WORK_BATCH_MAX
@@ -66,8 +71,23 @@
 #endif
 
 enum { PT_JITTER_CENTRE = 0, PT_JITTER_RNG = 1 };
-enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_SHADE = 4, PT_ST_DONE = 5 };
-enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_HAVE_REFRACT = 4 };  // parked frames
+enum { PT_ST_NEW_SAMPLE = 0, PT_ST_CLOSEST_DONE = 1, PT_ST_LIGHT = 2, PT_ST_SHADOW_DONE = 3, PT_ST_SHADE = 4, PT_ST_DONE = 5, PT_ST_WAIT_FORK = 6 };
+enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_FS_HAVE_REFRACT = 4,  // parked frames
+       PT_FS_FORKED = 8,      // the refracted subtree was handed to another lane (FORK instantiations): its colour arrives in the frame's mailbox
+       PT_FS_SEQ_SHIFT = 8 }; // bits 8..31: the lane's fork sequence number when the frame was parked (what the mailbox ticket is made of)
+// Fork / join of the reflective kernel (north_star: secondary rays compacted with ballot / popcount and re-enqueued through an LDS
+// queue). A dielectric hit spawns TWO subtrees, reflected and refracted (material.rs:216-303); one lane walks them one after the
+// other while lanes whose samples are finished idle until the wavefront's item ends. In FORK instantiations such a hit OFFERS its
+// refracted ray when it parks its frame; after every interpreter pass the wavefront matches offers and idle lanes by their ranks in
+// the two ballots (popcount of the lower lanes), the k-th offering lane writes its id to slot k of a queue in LDS, the k-th idle
+// lane reads it, takes the ray out of the owner's parked frame (LDS) and walks the subtree as a task rooted at that depth; its colour
+// goes to the owner's MAILBOX (slots 12..15 of the owner's HBM line for that depth: colour + ticket) and the owner, when its reflected
+// subtree is back, waits for the ticket (PT_ST_WAIT_FORK) and folds the two exactly as it would have (material.rs:305-309: same
+// operands, same order - which lane computed an operand does not change its bits). Only scenes whose recursion draws no random
+// numbers fork (no area light, no glossy material: the draw indices of the sampling contract follow the depth-first order).
+// A finished sample's colour waits in slots 12..14 of the lane's depth-10 line (frames of depth 10 never spawn, so that mailbox is
+// free): the lane's LDS frame is reused by the tasks it takes.
+enum { PT_H_MAIL = 12, PT_H_MAIL_TICKET = 15, PT_RESULT_DEPTH = PT_MAX_DEPTH };
 #define PT_FS_TEXEL 0x80000000u  // hit frame: bits 0..23 are the texel's R, G, B bytes; the diffuse colour is srgb_lut[] of them (texture.rs:162-168)
 #define PT_LIGHT_ROUND 32  // shadow-ray results are kept as one bit per light, 32 lights at a time
 
@@ -81,7 +101,7 @@ inline bool pt_interpreter_forced() {
 #endif
 }
 
-enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
+enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4, PT_RUN_INTERP_FORK = 5 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
 
 struct PtRenderArgs {
     PtSceneView scene;
@@ -110,6 +130,7 @@ struct PtRenderArgs {
     int32_t park_slots;              // parked recursion frames per lane kept in LDS (0 or 1; selects the PARK instantiation); older ones in `spill`
     int32_t four_waves;              // the instantiation compiled for 4 waves per SIMD (scenes without reflective materials only)
     int32_t run_variant;             // PT_RUN_* (pt_render_kernel.h): which kernel pt_render_common launches
+    uint32_t launch_nonce;           // differs from launch to launch of a context (24 bits): mailbox tickets of an earlier launch never match
     unsigned int* work_counter;
     unsigned int* overflow_flag;     // set to 1 by any lane that runs out of traversal stack
     uint32_t work_div;               // a wavefront takes (remaining items / work_div) items from work_counter at a time
@@ -128,6 +149,13 @@ struct PtLane {
     int32_t lo;        // parked frames of depth [lo, depth) are in LDS, those of [0, lo) in HBM
     PtRay ray;
     bool has_ray, ray_any;
+    // FORK instantiations only
+    bool offer;          // the frame parked in this pass has a refracted ray another lane may take
+    int32_t base;        // depth the lane's current task is rooted at: 0 = its own sample, d + 1 = a refracted subtree of a depth-d hit
+    uint32_t owner;      // a taken task's owner: its thread index in the block | the frame's depth << 16
+    uint32_t fork_seq;   // frames this lane has offered in this launch
+    uint64_t ticket;     // a taken task: what goes into the owner's mailbox with the colour
+    uint64_t wait_ticket;  // PT_ST_WAIT_FORK: what the lane waits for in its own mailbox (a lane walking a taken task may itself have forked)
 };
 
 // This lane's view of its two frame stores.
@@ -535,7 +563,23 @@ PT_HD PtVec3 pt_light_term(PtVec3 lcol, PtVec3 falloff, PtVec3 light_dir, double
 #define PT_ADVANCE_ATTR PT_HD
 #endif
 // TEX = false compiles the texture / normal-map path out (scenes without mapped materials).
-template <bool STATS, bool TEX, bool HIER = false, int PARK = 0>
+PT_HD uint64_t pt_fork_ticket(uint32_t nonce, uint32_t seq, int32_t depth) { return ((uint64_t)(nonce & 0xFFFFFFu) << 40) | ((uint64_t)(seq & 0xFFFFFFu) << 8) | (uint64_t)(depth & 0xFF) | (1ull << 39); }
+PT_HD uint64_t pt_mail_load(const double* slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(reinterpret_cast<const uint64_t*>(slot), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    uint64_t v; memcpy(&v, slot, 8); return v;
+#endif
+}
+PT_HD void pt_mail_store(double* slot, uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(slot), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    memcpy(slot, &v, 8);
+#endif
+}
+
+template <bool STATS, bool TEX, bool HIER = false, int PARK = 0, bool FORK = false>
 PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt) {
     const PtSceneView& sc = a.scene;
     L.has_ray = false;
@@ -545,8 +589,18 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
         if (returning) {
             // `value` = Ray::color() of the ray cast at depth L.depth
             returning = false;
+            if (FORK && L.depth == L.base && L.base > 0) {  // a taken subtree is finished: its colour to the owner's mailbox, then the ticket
+                double* mail = fr.spill + ((ptrdiff_t)(int32_t)(L.owner & 0xFFFFu) - (ptrdiff_t)PT_THREAD_IN_BLOCK()) * (PT_SPILL_DEPTHS * PT_SPILL_STRIDE) +
+                               (size_t)(L.owner >> 16) * PT_SPILL_STRIDE + PT_H_MAIL;
+                mail[0] = value.x; mail[1] = value.y; mail[2] = value.z;
+                pt_mail_store(mail + 3, L.ticket);
+                L.base = 0;
+                L.stage = PT_ST_DONE;
+                return;
+            }
             if (L.depth == 0) {  // render.rs:36-43: this sample's colour, summed with its chunk by pt_render_kernel
-                fr.set_l3(PT_L_VALUE, value);
+                if (FORK) fr.set_h3(PT_RESULT_DEPTH, PT_H_MAIL, value);  // the LDS frame is reused by the tasks this lane may take
+                else fr.set_l3(PT_L_VALUE, value);
                 L.stage = PT_ST_DONE;
                 return;
             }
@@ -575,8 +629,11 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 continue;
             }
             // the refracted ray (material.rs:286-303); its direction was worked out when the hit was shaded
-            L.ray.o = pt_v3(f[PT_H_P], f[PT_H_P + 1], f[PT_H_P + 2]);
-            L.ray.d = pt_v3(f[PT_H_DIR], f[PT_H_DIR + 1], f[PT_H_DIR + 2]);
+            const bool forked = FORK && (fstage & PT_FS_FORKED);
+            if (!forked) {
+                L.ray.o = pt_v3(f[PT_H_P], f[PT_H_P + 1], f[PT_H_P + 2]);
+                L.ray.d = pt_v3(f[PT_H_DIR], f[PT_H_DIR + 1], f[PT_H_DIR + 2]);
+            }
             // the frame waits again, now for the refracted subtree, with the reflected colour in place of the direction
             const double tag2 = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFRACT);
             if (in_lds) {
@@ -590,9 +647,21 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
                 fr.h(L.depth, PT_H_TAG) = tag2;
             }
             L.depth++;
+            if (forked) {  // another lane walks that subtree: wait for its colour (the ticket in this frame's mailbox)
+                L.wait_ticket = pt_fork_ticket(a.launch_nonce, fstage >> PT_FS_SEQ_SHIFT, L.depth - 1);
+                L.stage = PT_ST_WAIT_FORK;
+                return;
+            }
             L.ray_any = false; L.has_ray = true; L.stage = PT_ST_CLOSEST_DONE;
             if (STATS) cnt->refract++;
             return;
+        }
+        if (FORK && L.stage == PT_ST_WAIT_FORK) {
+            const double* mail = fr.spill + (size_t)(L.depth - 1) * PT_SPILL_STRIDE + PT_H_MAIL;
+            if (pt_mail_load(mail + 3) != L.wait_ticket) return;  // not yet: no ray this pass
+            value = pt_v3(mail[0], mail[1], mail[2]);
+            returning = true;  // as if the refracted ray's Ray::color() had just returned (material.rs:305-309 follows)
+            continue;
         }
         switch (L.stage) {
         case PT_ST_NEW_SAMPLE: {
@@ -739,7 +808,16 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             {
                 double f[PT_PARK_F64];
                 f[PT_H_COLOR] = color.x; f[PT_H_COLOR + 1] = color.y; f[PT_H_COLOR + 2] = color.z;
-                f[PT_H_TAG] = PtFrameRef::pack_tag(mat, PT_FS_WAIT_REFLECT | (have ? PT_FS_HAVE_REFRACT : 0));
+                uint32_t fs = PT_FS_WAIT_REFLECT | (have ? PT_FS_HAVE_REFRACT : 0);
+                if (FORK && have) {  // the refracted ray may be taken by an idle lane (pt_render_kernel matches offers and takers)
+                    L.fork_seq++;
+                    fs |= L.fork_seq << PT_FS_SEQ_SHIFT;
+                    L.offer = true;
+                    // whatever an earlier launch (of this or another process) left in this frame's mailbox must not pass for a
+                    // ticket: cleared here, by the owner, passes before any taker can write it
+                    pt_mail_store(&fr.h(L.depth, PT_H_MAIL_TICKET), 0ull);
+                }
+                f[PT_H_TAG] = PtFrameRef::pack_tag(mat, fs);
                 f[PT_H_DIR] = refract_dir.x; f[PT_H_DIR + 1] = refract_dir.y; f[PT_H_DIR + 2] = refract_dir.z;
                 f[PT_H_P] = P.x; f[PT_H_P + 1] = P.y; f[PT_H_P + 2] = P.z;
                 f[PT_H_SCHLICK] = schlick;
