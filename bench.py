@@ -80,10 +80,10 @@ def algorithmic_ops(st, n_lights, traversal):
 def kernel_name(st):
     """The instantiation pt_stats says ran (ABI 6: kernel_mode / kernel_variant), spelled like rocprofv3's kernel trace spells it."""
     v = st["kernel_variant"]
-    waves, interp, park, tex = v & 15, bool(v & 16), bool(v & 32), bool(v & 128)
+    waves, interp, park, tex, fork = v & 15, bool(v & 16), bool(v & 32), bool(v & 128), bool(v & 256)
     t = "true" if tex else "false"
     if interp:
-        return f"void pt_render_kernel<{st['kernel_mode']}, false, {t}, {1 if park else (2 if waves == 4 else 0)}>(PtRenderArgs)"
+        return f"void pt_render_kernel<{st['kernel_mode']}, false, {t}, {3 if fork else (1 if park else (2 if waves == 4 else 0))}>(PtRenderArgs)"
     return f"void pt_render_simple_kernel<{st['kernel_mode']}, false, {t}, {waves}>(PtRenderArgs)"
 
 

@@ -917,9 +917,18 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH;
     a.four_waves = (!c->spawns && c->four_waves) ? 1 : 0;
     if (const char* e = getenv("PORTRAYER_WAVES")) a.four_waves = (!c->spawns && atoi(e) == 4) ? 1 : 0;
-    if (kd_sem) a.four_waves = 0;
-    bool fork = c->forkable && a.park_slots;
-    if (const char* e = getenv("PORTRAYER_FORK")) fork = fork && atoi(e) > 0;  // 0: every subtree by the lane that spawned it (tests, measurements)
+    if (kd_sem) {
+        // The k-d semantics: mesh-free scenes with many nodes take the 4-wave straight-line kernel too (big-scene 35.7 -> 30.7 ms: the per-lane
+        // k-d walk waits on its own loads, a fourth wavefront per SIMD hides more of that than the 4 spilled registers cost); with mesh
+        // instances the walk needs the registers (167 at 3 waves). PORTRAYER_KD_WAVES=3|4 overrides.
+        a.four_waves = (a.scene.mode == PT_MODE_KD_NOMESH && !c->spawns && a.scene.n_nodes >= 256) ? 1 : 0;
+        if (const char* e = getenv("PORTRAYER_KD_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode == PT_MODE_KD_NOMESH && !c->spawns) ? 1 : 0;
+    }
+    // Fork / join of refracted subtrees (pt_shade.h) is built, parity-green and OFF by default: it fills the idle lanes and still loses
+    // (transmission-refraction 11.4 -> 8.6 Gray/s, profiles/r03/notes.md section 4): the subtrees other lanes walk are other rays, and the
+    // one walk per wavefront pays for the union of their paths. PORTRAYER_FORK=1 switches it on for scenes that qualify.
+    bool fork = false;
+    if (const char* e = getenv("PORTRAYER_FORK")) fork = c->forkable && a.park_slots && atoi(e) > 0;
     if (c->launch_seq == 0) c->launch_seq = (uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u;  // a different starting point in every context
     a.launch_nonce = ++c->launch_seq;
     if (c->spawns) a.run_variant = a.park_slots ? (fork ? PT_RUN_INTERP_FORK : PT_RUN_INTERP_PARK) : PT_RUN_INTERP;

@@ -146,21 +146,10 @@ PT_HD bool pt_cone_hit(const PtRay& r, double start, double end, double* t_out, 
 //      (x - y == -(y - x) and x / -y == -(x / y) exactly), followed by the type's own acceptance test.
 // `part` is the tag pt_prim_surface() expects.
 //
-// Written WITHOUT per-lane branches where the reference has early returns: a wavefront executes both sides of a divergent `if`
-// anyway, and every such region costs scalar instructions to save, narrow and restore the execution mask - on a path where the
-// CU's one scalar unit is as busy as its vector units (profiles/r03/notes.md). Every accepted value is still produced by exactly
-// the reference's operations on that lane; what a rejected lane computes on the way is discarded.
-PT_HD bool pt_lanes_any(bool x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __ballot(x) != 0ull;
-#else
-    return x;
-#endif
-}
+// (A version without per-lane branches - every slot's arithmetic for every lane, selects instead of `continue` - was measured in
+// round 3: fewer scalar instructions, more vector ones, big-scene 34.4 -> 33.3 Gray/s, KD 35.9 -> 36.2 ms. Not kept.)
 PT_HD bool pt_unit_prim_hit(uint32_t type, const PtRay& r, double start, double end, double* t_out, uint32_t* part) {
     bool found = false;
-    double t_best = 0.0;
-    uint32_t p_best = 0;
     if (type == PT_SPHERE || type == PT_CYLINDER || type == PT_CONE) {
         double a, b, c;
         if (type == PT_SPHERE) {
@@ -178,26 +167,11 @@ PT_HD bool pt_unit_prim_hit(uint32_t type, const PtRay& r, double start, double 
             b = -8.0 * h_sqr * (d.x * o.x + d.z * o.z) - 4.0 * r_sqr * (d.y * HEIGHT - 2.0 * d.y * o.y);
             c = -4.0 * h_sqr * (o.x * o.x + o.z * o.z) + r_sqr * (h_sqr - 4.0 * HEIGHT * o.y + 4.0 * o.y * o.y);
         }
-        // roots::find_roots_quadratic + find_in_range (pt_first_root): the first root in ascending order inside [start, end)
-        const double disc = b * b - 4.0 * a * c;
-        double t = 0.0;
-        bool got;
-        if (pt_lanes_any(a == 0.0 || disc == 0.0)) {  // a linear equation or a double root on some lane: the routine with its special cases
-            got = pt_first_root(a, b, c, start, end, &t);
-        } else {
-            const double a2x2 = 2.0 * a;
-            const double sq = sqrt(disc);  // NaN where disc < 0: that lane's result is discarded below
-            const double x1 = (-b - sq) / a2x2;
-            const double x2 = (-b + sq) / a2x2;
-            const double lo = x1 < x2 ? x1 : x2;
-            const double hi = x1 < x2 ? x2 : x1;
-            const bool in_lo = pt_in_range(start, end, lo), in_hi = pt_in_range(start, end, hi);
-            t = in_lo ? lo : hi;
-            got = !(disc < 0.0) && (in_lo || in_hi);
+        double t;
+        if (pt_first_root(a, b, c, start, end, &t)) {  // first root only (quirk Q1)
+            double y = r.o.y + r.d.y * t;
+            if (type == PT_SPHERE || !(y > 0.5 || y < -0.5)) { end = t; *t_out = t; *part = 0; found = true; }
         }
-        const double y = r.o.y + r.d.y * t;
-        const bool acc = got && (type == PT_SPHERE || !(y > 0.5 || y < -0.5));  // first root only (quirk Q1)
-        end = acc ? t : end; t_best = acc ? t : t_best; found = acc;
     }
     // slots the type uses, bit k = slot k (+x, -x, +y, -y, +z, -z)
     const uint32_t slots = type == PT_CUBE ? 0x3Fu : (type == PT_CYLINDER ? 0x0Cu : (type == PT_CONE ? 0x08u : (type == PT_PLANE ? 0x04u : 0u)));
@@ -210,17 +184,18 @@ PT_HD bool pt_unit_prim_hit(uint32_t type, const PtRay& r, double start, double 
         if (type == PT_PLANE) h = 0.0;
         double o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
         double d = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
-        const double t = (h - o) / d;
-        const PtVec3 p = pt_ray_at(r, t);
+        double t = (h - o) / d;
+        if (!pt_in_range(start, end, t)) continue;
+        PtVec3 p = pt_ray_at(r, t);
         bool ok;
         if (type == PT_CUBE) ok = -radius <= p.x && p.x <= radius && -radius <= p.y && p.y <= radius && -radius <= p.z && p.z <= radius;
         else if (type == PT_PLANE) ok = -radius <= p.x && p.x <= radius && -radius <= p.z && p.z <= radius;
         else ok = !((p.x * p.x + p.z * p.z) > 0.25);
-        const bool acc = pt_in_range(start, end, t) && ok;
-        end = acc ? t : end; t_best = acc ? t : t_best; found = found || acc;
-        p_best = acc ? (type == PT_CUBE ? (uint32_t)k : (type == PT_CYLINDER ? (uint32_t)(k - 1) : (type == PT_CONE ? 1u : 0u))) : p_best;
+        if (ok) {
+            end = t; *t_out = t; found = true;
+            *part = type == PT_CUBE ? (uint32_t)k : (type == PT_CYLINDER ? (uint32_t)(k - 1) : (type == PT_CONE ? 1u : 0u));
+        }
     }
-    *t_out = t_best; *part = p_best;
     return found;
 }
 

@@ -331,8 +331,8 @@ static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_
         if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 2>, lds, a, n_cu, stream, grid_out, launch);
         return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
 #endif
-    case PT_RUN_LINE4:  // the k-d tree semantics (per-lane walk) have no 4-wave instantiation: measured slower there
-        if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 4>, lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_LINE4:  // the k-d tree semantics with mesh instances (per-lane walk through two levels of trees) have no 4-wave instantiation
+        if constexpr (MODE != PT_MODE_KD) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 4>, lds, a, n_cu, stream, grid_out, launch);
         [[fallthrough]];
     default: return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 3>, lds, a, n_cu, stream, grid_out, launch);
     }

@@ -148,6 +148,55 @@ PT_HD PtRay32 pt_ray32(const PtRay& r) {
     return q;
 }
 
+// ---- The same idea with the margins folded into the per-ray constants (round 3; the derivation is with pt_slab_pk2 below): per axis
+// a pair (i, c) for a box's LOWER plane and one for its UPPER plane, chosen by the direction's sign so that min / max of the two
+// fmas are conservative entering / leaving parameters without any widening afterwards.
+typedef float pt_f32x2 __attribute__((ext_vector_type(2)));
+struct PtRayPk {
+    pt_f32x2 a[3], b[3];  // per axis (i, c) for the children's lower planes / upper planes
+};
+PT_HD float pt_rcp_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// returns 0: axis switched off, 1: positive direction, 2: negative direction
+PT_HD int pt_raypk_axis(double o, double d, pt_f32x2* a, pt_f32x2* b) {
+    const float i0 = pt_rcp_f32((float)d);
+    if (!(fabsf(i0) <= 1e18f)) {
+        a->x = 0.0f; a->y = -INFINITY; b->x = 0.0f; b->y = INFINITY;
+        return 0;
+    }
+    const float k = 4.76837158203125e-7f;  // 2^-21
+    const float in = i0 - i0 * k, fi = i0 + i0 * k;
+    float cn = (float)(-(o * (double)in)), cf = (float)(-(o * (double)fi));
+    cn = cn - (fabsf(cn) * 2.4e-7f + 1e-37f);
+    cf = cf + (fabsf(cf) * 2.4e-7f + 1e-37f);
+    const bool neg = i0 < 0.0f;  // entering through the upper plane
+    a->x = neg ? fi : in; a->y = neg ? cf : cn;
+    b->x = neg ? in : fi; b->y = neg ? cn : cf;
+    return neg ? 2 : 1;
+}
+PT_HD PtRayPk pt_raypk(const PtRay& r) {  // without the wavefront's view: for walks that always take the per-lane form
+    PtRayPk q;
+    pt_raypk_axis(r.o.x, r.d.x, &q.a[0], &q.b[0]);
+    pt_raypk_axis(r.o.y, r.d.y, &q.a[1], &q.b[1]);
+    pt_raypk_axis(r.o.z, r.d.z, &q.a[2], &q.b[2]);
+    return q;
+}
+// The per-lane form of the slab test with those constants, against a segment [tmin, tmax] of the ray (both already rounded outward
+// by the caller): the conservative culls of the k-d walks. 6 fmas + 6 min / max + 4 + 1 compare.
+PT_HD bool pt_slab_seg_pk(const float* lo, const float* hi, const PtRayPk& q, float tmin, float tmax) {
+    const float ax = __builtin_fmaf(lo[0], q.a[0].x, q.a[0].y), bx = __builtin_fmaf(hi[0], q.b[0].x, q.b[0].y);
+    const float ay = __builtin_fmaf(lo[1], q.a[1].x, q.a[1].y), by = __builtin_fmaf(hi[1], q.b[1].x, q.b[1].y);
+    const float az = __builtin_fmaf(lo[2], q.a[2].x, q.a[2].y), bz = __builtin_fmaf(hi[2], q.b[2].x, q.b[2].y);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return !(tn > tf);
+}
+
 // Slab test of one child box against [0, tmax] in f32. Conservative by construction (see PtRay32);
 // the final interval is widened by 2^-20 relative (fma + reciprocal roundings are < 2^-22), NaNs
 // cannot arise from finite boxes, and the comparison is written so that an unordered result accepts
@@ -334,13 +383,13 @@ PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay
     int32_t cur = m.kd_root;
     const double extent = m.kd_extent;
     const double end0 = end;  // a pending far side's range end = the start of the entry below it, or end0
-    const PtRay32 q = pt_ray32(local);
+    const PtRayPk q = pt_raypk(local);
     for (;;) {
         const PtKdNode n = sc.mkd[cur];
         // conservative culls as in pt_trace_kd: a subtree / a triangle whose box the segment [start, end) does not reach reports no hit
         float seg0 = (float)start, seg1 = (float)end;
         seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
-        if (sc.mkd_box && !pt_slab32_segment(n.box, n.box + 3, q, seg0, seg1)) {
+        if (sc.mkd_box && !pt_slab_seg_pk(n.box, n.box + 3, q, seg0, seg1)) {
             if (STATS) cnt->kd_culled++;
         } else if (n.axis < 0) {  // leaf: [T]::ray_hit (ray.rs:50-63) over the leaf's triangles, in order, strict shrinking end
             if (STATS) cnt->n_leaf++;
@@ -350,7 +399,7 @@ PT_HD bool pt_kdmesh_hit(const PtSceneView& sc, const PtMeshInfo& m, const PtRay
                 uint32_t tri = sc.mkd_items[n.first + i];
                 if (sc.mkd_item_box) {
                     const float* ib = sc.mkd_item_box + 6 * (size_t)(n.first + i);
-                    if (!pt_slab32_segment(ib, ib + 3, q, seg0, seg1)) continue;
+                    if (!pt_slab_seg_pk(ib, ib + 3, q, seg0, seg1)) continue;
                 }
                 double tt, beta, gamma;
                 if (STATS) cnt->n_tri++;
@@ -639,14 +688,14 @@ struct PtKdWalker {
     double start, end;
     int sp;
     int32_t cur;
-    PtRay32 q;
+    PtRayPk q;
     static constexpr int32_t NONE = -1;
 
     PT_HD bool begin(const PtSceneView& sc, const PtRay& ray) {
         best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0;
         start = PT_EPSILON; end = INFINITY;  // ray.rs:140
         sp = 0; cur = 0;
-        q = pt_ray32(ray);
+        q = pt_raypk(ray);
         return true;
     }
 
@@ -665,7 +714,7 @@ struct PtKdWalker {
         // the reference would find out by walking it - then, in a leaf, each referenced node's own box.
         float seg0 = (float)start, seg1 = (float)end;
         seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
-        if (sc.kd_box && !pt_slab32_segment(n.box, n.box + 3, q, seg0, seg1)) {
+        if (sc.kd_box && !pt_slab_seg_pk(n.box, n.box + 3, q, seg0, seg1)) {
             if (STATS) cnt->kd_culled++;
         } else if (n.axis < 0) {  // Leaf: ray.rs:87-99 fold over the leaf's nodes, reference order, strict ends
             if (STATS) cnt->n_leaf++;
@@ -679,7 +728,7 @@ struct PtKdWalker {
                 if (sc.node_box) {
                     const float* b = sc.node_box + 6 * (size_t)(n.first + i);
                     if (STATS) cnt->n_bbox++;
-                    if (!pt_slab32_segment(b, b + 3, q, seg0, seg1)) continue;
+                    if (!pt_slab_seg_pk(b, b + 3, q, seg0, seg1)) continue;
                 }
                 PtHit lb; lb.t = end; lb.node = PT_NO_HIT; lb.sub = 0;
                 if (pt_test_node<STATS>(sc, item, ray, start, lb, any, stk, sp, cnt)) {
@@ -737,7 +786,7 @@ struct PtKdWalker {
             // the reference would find out by walking it - then, in a leaf, each referenced node's own box.
             seg0 = (float)start; seg1 = (float)end;
             seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
-            if (sc.kd_box && !pt_slab32_segment(n.box, n.box + 3, q, seg0, seg1)) {
+            if (sc.kd_box && !pt_slab_seg_pk(n.box, n.box + 3, q, seg0, seg1)) {
                 if (STATS) cnt->kd_culled++;
                 cur = NONE;
                 continue;
@@ -778,7 +827,7 @@ struct PtKdWalker {
             if (sc.node_box) {
                 const float* b = sc.node_box + 6 * (size_t)(n.first + i);
                 if (STATS) cnt->n_bbox++;
-                if (!pt_slab32_segment(b, b + 3, q, seg0, seg1)) continue;
+                if (!pt_slab_seg_pk(b, b + 3, q, seg0, seg1)) continue;
             }
             PtHit lb; lb.t = end; lb.node = PT_NO_HIT; lb.sub = 0;
             if (pt_test_node<STATS, MESH>(sc, item, ray, start, lb, any, stk, sp, cnt)) {
@@ -955,46 +1004,11 @@ PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, cons
 // switched off: A = (0, -inf), B = (0, +inf).
 // A step is 6 packed fmas + 20 min / max + 3 compares for both children.
 // ------------------------------------------------------------------------------------------------
-typedef float pt_f32x2 __attribute__((ext_vector_type(2)));
-struct PtRayPk {
-    pt_f32x2 a[3], b[3];  // per axis (i, c) for the children's lower planes / upper planes
-};
-PT_HD float pt_rcp_f32(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcpf(x);
-#else
-    return 1.0f / x;
-#endif
-}
-// returns 0: axis switched off, 1: positive direction, 2: negative direction
-PT_HD int pt_raypk_axis(double o, double d, pt_f32x2* a, pt_f32x2* b) {
-    const float i0 = pt_rcp_f32((float)d);
-    if (!(fabsf(i0) <= 1e18f)) {
-        a->x = 0.0f; a->y = -INFINITY; b->x = 0.0f; b->y = INFINITY;
-        return 0;
-    }
-    const float k = 4.76837158203125e-7f;  // 2^-21
-    const float in = i0 - i0 * k, fi = i0 + i0 * k;
-    float cn = (float)(-(o * (double)in)), cf = (float)(-(o * (double)fi));
-    cn = cn - (fabsf(cn) * 2.4e-7f + 1e-37f);
-    cf = cf + (fabsf(cf) * 2.4e-7f + 1e-37f);
-    const bool neg = i0 < 0.0f;  // entering through the upper plane
-    a->x = neg ? fi : in; a->y = neg ? cf : cn;
-    b->x = neg ? in : fi; b->y = neg ? cn : cf;
-    return neg ? 2 : 1;
-}
 // Constants of `r` for this lane. *oct (wave-uniform): how the directions of the rays of the lanes in `lanes` relate to the axes -
 // bit a set: they all enter slabs of axis a through the UPPER plane (negative direction), clear: through the lower one; PT_OCT_MIXED
 // when some axis has rays of both signs among those lanes. Rays through one pixel, or from neighbouring points to one light,
 // nearly always share their signs, and then the tree step needs no min / max to tell entering from leaving (pt_slab_pk2).
 #define PT_OCT_MIXED 8
-PT_HD PtRayPk pt_raypk(const PtRay& r) {  // without the wavefront's view: for walks that always take the per-lane form
-    PtRayPk q;
-    pt_raypk_axis(r.o.x, r.d.x, &q.a[0], &q.b[0]);
-    pt_raypk_axis(r.o.y, r.d.y, &q.a[1], &q.b[1]);
-    pt_raypk_axis(r.o.z, r.d.z, &q.a[2], &q.b[2]);
-    return q;
-}
 PT_HD PtRayPk pt_raypk(const PtRay& r, bool lanes, int* oct) {
     PtRayPk q;
     const int sx = pt_raypk_axis(r.o.x, r.d.x, &q.a[0], &q.b[0]);

@@ -35,6 +35,7 @@ def test_kernel_name_follows_pt_stats(bench):
     assert bench.kernel_name({"kernel_mode": 3, "kernel_variant": 4}) == "void pt_render_simple_kernel<3, false, false, 4>(PtRenderArgs)"
     assert bench.kernel_name({"kernel_mode": 1, "kernel_variant": 3 | 128}) == "void pt_render_simple_kernel<1, false, true, 3>(PtRenderArgs)"
     assert bench.kernel_name({"kernel_mode": 4, "kernel_variant": 3 | 16 | 32 | 128}) == "void pt_render_kernel<4, false, true, 1>(PtRenderArgs)"
+    assert bench.kernel_name({"kernel_mode": 4, "kernel_variant": 3 | 16 | 32 | 128 | 256}) == "void pt_render_kernel<4, false, true, 3>(PtRenderArgs)"
     assert bench.kernel_name({"kernel_mode": 3, "kernel_variant": 4 | 16}) == "void pt_render_kernel<3, false, false, 2>(PtRenderArgs)"
     assert bench.kernel_name({"kernel_mode": 7, "kernel_variant": 3 | 16}) == "void pt_render_kernel<7, false, false, 0>(PtRenderArgs)"
 

@@ -228,3 +228,32 @@ def test_recursion_frames_all_in_hbm(oracle, host, H, monkeypatch, scene_name, m
     bad = (rgb != ref.rgb).any(axis=2)
     assert bad.sum() <= (2 if scene_name == "textured-1" else 0)  # sphere uv through atan2 / acos: see test_random_textured_scene_matches_oracle
     assert np.array_equal(plain, rgb)
+
+
+@pytest.mark.parametrize("scene_name,mode", [("transmission-refraction", "flat"), ("transmission-refraction", "hier"), ("transmission-refraction", "kd")])
+def test_fork_join_of_refracted_subtrees_matches_oracle(oracle, host, H, monkeypatch, scene_name, mode):
+    """PORTRAYER_FORK=1: lanes whose samples are finished take the refracted subtrees busy lanes offer (LDS queue, ballot ranks,
+    mailboxes in HBM; pt_shade.h). Which lane walks a subtree must not change a bit: image, f64 means and ray counts == the oracle's,
+    and == the render without forking. 64 samples per pixel: a wavefront is one pixel, offers and idle lanes meet inside it."""
+    from example_scenes import TEXTURED_EXAMPLES
+    from scene_dsl import default_background
+    scene, cam = TEXTURED_EXAMPLES[scene_name]()[:2]
+    tr, om = {"flat": (H.TRAVERSE_FLAT, oracle.MODE_FLAT), "kd": (H.TRAVERSE_KD, oracle.MODE_KD), "hier": (H.TRAVERSE_HIER, oracle.MODE_HIER)}[mode]
+    w, h, samples = 96, 54, 64
+    bg = default_background(w, h)
+    r = host.Renderer(host_glue.host_scene(scene), tr, kd_depth=5)
+    plain, plain_linear, st0 = r.render(host_glue.cam10(cam), w, h, bg, samples=samples, seed=3, sample_mode=H.SAMPLE_RNG, stats=True)
+    assert not st0["kernel_variant"] & H.KERNEL_FORK
+    monkeypatch.setenv("PORTRAYER_FORK", "1")
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, bg, samples=samples, seed=3, sample_mode=H.SAMPLE_RNG, stats=True)
+    fast, fast_linear, st2 = r.render(host_glue.cam10(cam), w, h, bg, samples=samples, seed=3, sample_mode=H.SAMPLE_RNG)  # the non-counting instantiation
+    r.close()
+    assert st["kernel_variant"] & H.KERNEL_FORK and st2["kernel_variant"] & H.KERNEL_FORK
+    assert np.array_equal(rgb, plain) and np.array_equal(linear, plain_linear), "forking changed the picture"
+    assert np.array_equal(fast, rgb) and np.array_equal(fast_linear, linear)
+    for k in ("primary", "shadow", "reflect", "refract", "hits", "depth11_skipped"):
+        assert st[k] == st0[k], k
+    ref = oracle.render(scene, cam, w, h, samples=samples, seed=3, jitter=oracle.JITTER_RNG, mode=om, kd_depth=5)
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert np.array_equal(rgb, ref.rgb)

@@ -70,7 +70,7 @@ def test_transmission_refraction_at_the_timed_size(oracle, host, H):
     again, _, timed = r.render(sc.camera, w, h, bg, samples=samples, seed=0, sample_mode=H.SAMPLE_RNG, want_linear=False)
     r.close()
     assert np.array_equal(rgb, again)
-    assert timed["kernel_variant"] == (3 | H.KERNEL_INTERPRETER | H.KERNEL_PARK | H.KERNEL_TEXTURED | H.KERNEL_FORK), "reflective, dielectric, textured, point lights: the interpreter with a parked frame in LDS and fork / join of refracted subtrees"
+    assert timed["kernel_variant"] == (3 | H.KERNEL_INTERPRETER | H.KERNEL_PARK | H.KERNEL_TEXTURED), "reflective, textured: the interpreter with a parked frame in LDS (fork / join is opt-in)"
     assert st["primary"] == w * h * samples and st["reflect"] > 0 and st["refract"] > 0 and st["stack_overflow"] == 0
     ps = oracle.pack_arrays(sc.export())
     check_pixels_in_parallel(oracle, ps, sc.camera, rgb, w, h, samples, oracle.MODE_FLAT, pick_pixels(rgb, 16, 16))
