@@ -183,7 +183,8 @@ struct pt_context {
     bool spawns = false;       // some material is reflective: hits spawn rays, so the cost of a pixel varies by orders of magnitude
     bool forkable = false;     // ... and no hit draws random numbers after the jitter (no area light, no glossy material): refracted subtrees may be walked by other lanes
     uint32_t launch_seq = 0;   // PtRenderArgs::launch_nonce
-    bool four_waves = false;   // traversal-heavy scene without reflective materials, flat_scene / hierarchical semantics: the 4-waves-per-SIMD kernel
+    bool four_waves = false;   // traversal-heavy scene without reflective materials, flat_scene / hierarchical semantics: a kernel compiled for more than 3 waves per SIMD
+    bool five_waves = false;   // ... mesh-free: 5 waves per SIMD (96 registers)
     PtSceneView view;
     bool have_scene = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -664,8 +665,14 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         uint64_t instanced_tris = 0;
         for (uint32_t i = 0; i < n; i++)
             if (s->prim_type[i] == PT_PRIM_MESH || s->prim_type[i] == PT_PRIM_KDMESH) instanced_tris += s->mesh_tri_off[s->prim_data[i] + 1] - s->mesh_tri_off[s->prim_data[i]];
-        // hierarchical semantics: big-scene measured 2 % slower at 4 waves, the 1.25 M-triangle soup 4 % faster
-        c->four_waves = !c->spawns && ((traverse == PT_TRAVERSE_FLAT && (n >= 256 || instanced_tris >= 65536)) || (traverse == PT_TRAVERSE_HIER && instanced_tris >= 65536));
+        // hierarchical semantics (round 3, straight-line kernel): mesh-free scenes with many nodes gain like flat_scene ones (big-scene 25.7 ->
+        // 29.4 Gray/s at 4 waves); with mesh instances the walk carries a second ray and spills at 128 registers (macho-cows 16.4 -> 12.0) unless
+        // the triangle trees dominate (the 1.25 M-triangle soup: equal)
+        c->four_waves = !c->spawns && ((traverse == PT_TRAVERSE_FLAT && (n >= 256 || instanced_tris >= 65536)) ||
+                                       (traverse == PT_TRAVERSE_HIER && ((s->n_meshes == 0 && n >= 256) || instanced_tris >= 65536)));
+        // mesh-free scenes go one further: 5 waves per SIMD (96 registers, 17 of the kernel's spilled; big-scene 34.4 -> 37.0, hierarchical
+        // 29.4 -> 32.5 Gray/s; the k-d walk, 50 spilled, loses and stays at 4)
+        c->five_waves = c->four_waves && s->n_meshes == 0 && traverse != PT_TRAVERSE_KD;
     }
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
     {   // fork / join of refracted subtrees (pt_shade.h) needs a recursion that draws no random numbers and a dielectric material to be of use
@@ -915,14 +922,17 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // Scenes whose hits spawn rays need the interpreter kernel (3 waves per SIMD); the others run the straight-line kernel at 3 or
     // 4 waves per SIMD. PORTRAYER_INTERP=1 (builds with -DPT_KEEP_INTERP): the interpreter on those too, for A/B runs.
     const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH;
-    a.four_waves = (!c->spawns && c->four_waves) ? 1 : 0;
-    if (const char* e = getenv("PORTRAYER_WAVES")) a.four_waves = (!c->spawns && atoi(e) == 4) ? 1 : 0;
+    a.four_waves = (!c->spawns && c->four_waves) ? (c->five_waves ? 5 : 4) : 0;
+    if (const char* e = getenv("PORTRAYER_WAVES")) {
+        const int wv = atoi(e);
+        a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? 5 : 4) : 0;
+    }
     if (kd_sem) {
         // The k-d semantics: mesh-free scenes with many nodes take the 4-wave straight-line kernel too (big-scene 35.7 -> 30.7 ms: the per-lane
         // k-d walk waits on its own loads, a fourth wavefront per SIMD hides more of that than the 4 spilled registers cost); with mesh
         // instances the walk needs the registers (167 at 3 waves). PORTRAYER_KD_WAVES=3|4 overrides.
-        a.four_waves = (a.scene.mode == PT_MODE_KD_NOMESH && !c->spawns && a.scene.n_nodes >= 256) ? 1 : 0;
-        if (const char* e = getenv("PORTRAYER_KD_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode == PT_MODE_KD_NOMESH && !c->spawns) ? 1 : 0;
+        a.four_waves = (a.scene.mode == PT_MODE_KD_NOMESH && !c->spawns && a.scene.n_nodes >= 256) ? 4 : 0;
+        if (const char* e = getenv("PORTRAYER_KD_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode == PT_MODE_KD_NOMESH && !c->spawns) ? 4 : 0;
     }
     // Fork / join of refracted subtrees (pt_shade.h) is built, parity-green and OFF by default: it fills the idle lanes and still loses
     // (transmission-refraction 11.4 -> 8.6 Gray/s, profiles/r03/notes.md section 4): the subtrees other lanes walk are other rays, and the
@@ -933,8 +943,8 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.launch_nonce = ++c->launch_seq;
     if (c->spawns) a.run_variant = a.park_slots ? (fork ? PT_RUN_INTERP_FORK : PT_RUN_INTERP_PARK) : PT_RUN_INTERP;
     else if (pt_interpreter_forced()) a.run_variant = a.four_waves ? PT_RUN_INTERP4 : PT_RUN_INTERP;
-    else a.run_variant = a.four_waves ? PT_RUN_LINE4 : PT_RUN_LINE3;
-    size_t block_budget = a.four_waves ? 39 * 1024 : 52 * 1024;  // 3 x 52 KB or 4 x 39 KB of the CU's 160 KB
+    else a.run_variant = a.four_waves == 5 ? PT_RUN_LINE5 : (a.four_waves ? PT_RUN_LINE4 : PT_RUN_LINE3);
+    size_t block_budget = a.four_waves == 5 ? 31 * 1024 : (a.four_waves ? 39 * 1024 : 52 * 1024);  // 3 x 52 KB, 4 x 39 KB or 5 x 31 KB of the CU's 160 KB
     if (const char* e = getenv("PORTRAYER_LDS_BUDGET_KB")) block_budget = (size_t)std::max(16, std::min(160, atoi(e))) * 1024;  // experiment: 80 = two blocks per CU
     const size_t frame_bytes = (size_t)(PT_LDS_FRAME_F64 + a.park_slots * PT_PARK_F64) * PT_BLOCK * 8;
     int lds_cap = block_budget > frame_bytes ? (int)((block_budget - frame_bytes) / (PT_BLOCK * 4)) : 0;
@@ -979,7 +989,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.counters = (PtCounters*)((char*)c->misc.p + 256);
     a.work_queues = (unsigned int*)((char*)c->misc.p + 256 + sizeof(PtCounters));
     c->last_mode = (uint32_t)a.scene.mode;
-    c->last_variant = (a.four_waves ? 4u : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4) ? 0u : PT_KERNEL_INTERPRETER) |
+    c->last_variant = (a.four_waves ? (uint32_t)a.four_waves : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4 || a.run_variant == PT_RUN_LINE5) ? 0u : PT_KERNEL_INTERPRETER) |
                       ((a.run_variant == PT_RUN_INTERP_PARK || a.run_variant == PT_RUN_INTERP_FORK) ? PT_KERNEL_PARK : 0u) | (a.run_variant == PT_RUN_INTERP_FORK ? PT_KERNEL_FORK : 0u) | (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));

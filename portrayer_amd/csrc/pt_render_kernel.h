@@ -36,6 +36,9 @@
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 0  // experiments: -DPT_MIN_WAVES=2 / 3 / 4 for every instantiation
 #endif
+#ifndef PT_LINE_TOP_WAVES
+#define PT_LINE_TOP_WAVES 5  // waves per SIMD of the mesh-free straight-line kernels' densest instantiation (experiment: 6, with PORTRAYER_LDS_BUDGET_KB=26)
+#endif
 #ifndef PT_INTERP_WAVES
 #define PT_INTERP_WAVES 3  // experiments: -DPT_INTERP_WAVES=2 compiles the interpreter kernels (VAR 0, 1, 3) for 2 waves per SIMD (256 VGPRs)
 #endif
@@ -316,7 +319,7 @@ static hipError_t pt_launch_kernel(Kernel kernel, size_t lds, const PtRenderArgs
 //   PT_RUN_INTERP / PT_RUN_INTERP_PARK   the interpreter kernel (scenes with reflective materials: hits spawn rays), every parked
 //                                        recursion frame in HBM / the youngest in LDS; 3 waves per SIMD
 //   PT_RUN_INTERP_FORK                   PT_RUN_INTERP_PARK + fork / join: idle lanes take the refracted subtrees busy lanes offer (pt_shade.h)
-//   PT_RUN_LINE3 / PT_RUN_LINE4          the straight-line kernel of pt_render_simple.h (hits spawn nothing), 3 / 4 waves per SIMD
+//   PT_RUN_LINE3 / PT_RUN_LINE4 / _LINE5 the straight-line kernel of pt_render_simple.h (hits spawn nothing), 3 / 4 / 5 waves per SIMD
 //   PT_RUN_INTERP4                       -DPT_KEEP_INTERP builds only: the interpreter at 4 waves per SIMD on a scene without reflective
 //                                        materials (what round 2 timed), for A/B runs against the straight-line kernel
 template <int MODE, bool STATS, bool TEX>
@@ -331,6 +334,9 @@ static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_
         if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 2>, lds, a, n_cu, stream, grid_out, launch);
         return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
 #endif
+    case PT_RUN_LINE5:  // mesh-free scenes in the flat_scene / hierarchical semantics: 96 registers, 5 waves per SIMD
+        if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>, lds, a, n_cu, stream, grid_out, launch);
+        [[fallthrough]];
     case PT_RUN_LINE4:  // the k-d tree semantics with mesh instances (per-lane walk through two levels of trees) have no 4-wave instantiation
         if constexpr (MODE != PT_MODE_KD) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 4>, lds, a, n_cu, stream, grid_out, launch);
         [[fallthrough]];

@@ -101,7 +101,7 @@ inline bool pt_interpreter_forced() {
 #endif
 }
 
-enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4, PT_RUN_INTERP_FORK = 5 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
+enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4, PT_RUN_INTERP_FORK = 5, PT_RUN_LINE5 = 6 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
 
 struct PtRenderArgs {
     PtSceneView scene;
@@ -128,7 +128,7 @@ struct PtRenderArgs {
     uint32_t* stack_spill;           // traversal-stack entries beyond the LDS part, entry x n_lanes
     int32_t stack_lds_cap;           // entries per lane kept in LDS; the rest (up to scene.stack_cap) in stack_spill
     int32_t park_slots;              // parked recursion frames per lane kept in LDS (0 or 1; selects the PARK instantiation); older ones in `spill`
-    int32_t four_waves;              // the instantiation compiled for 4 waves per SIMD (scenes without reflective materials only)
+    int32_t four_waves;              // the instantiation compiled for more than 3 waves per SIMD (scenes without reflective materials only): 0, or 4 / 5 = the waves
     int32_t run_variant;             // PT_RUN_* (pt_render_kernel.h): which kernel pt_render_common launches
     uint32_t launch_nonce;           // differs from launch to launch of a context (24 bits): mailbox tickets of an earlier launch never match
     unsigned int* work_counter;
