@@ -47,6 +47,7 @@ WORKLOADS = {
     "primitives": ("primitives-simple", 0, 800, 600, 1),
     "triangle": ("single-triangle", 0, 256, 256, 1),
     "aquarium": ("transmission-refraction", 0, 1920, 1080, 16),  # glass + water to depth 10, textured KDMesh fish, normal maps
+    "water-glass": ("water-glass", 0, 1920, 1080, 16),  # glossy table, glass, water, textures; FLAT and HIER differ visibly on this one
     # synthetic, not reference scenes: the big-scene generator over cow.obj instances / baked triangles
     "big-mesh": ("synthetic:big-mesh", 6, 1920, 1080, 16),
     "big-soup": ("synthetic:big-soup", 6, 1920, 1080, 16),
@@ -84,7 +85,9 @@ def kernel_name(st):
     t = "true" if tex else "false"
     if interp:
         return f"void pt_render_kernel<{st['kernel_mode']}, false, {t}, {3 if fork else (1 if park else (2 if waves == 4 else 0))}>(PtRenderArgs)"
-    return f"void pt_render_simple_kernel<{st['kernel_mode']}, false, {t}, {waves}>(PtRenderArgs)"
+    if v & 512:
+        return f"void pt_render_simple_kernel<{st['kernel_mode']}, false, {t}, {waves}, true>(PtRenderArgs)"
+    return f"void pt_render_simple_kernel<{st['kernel_mode']}, false, {t}, {waves}, false>(PtRenderArgs)"
 
 
 def measured_profile(key, kernel):

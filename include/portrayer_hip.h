@@ -191,7 +191,8 @@ enum { PT_KERNEL_MODE_FLAT = 1, PT_KERNEL_MODE_KD = 2, PT_KERNEL_MODE_FLAT_NOMES
  * interpreter that scenes with reflective materials need (material.rs:216-303), else the straight-line kernel; PT_KERNEL_PARK:
  * a parked recursion frame per lane in LDS; PT_KERNEL_COUNTING: the counting build (collect_stats); PT_KERNEL_TEXTURED */
 enum { PT_KERNEL_WAVES_MASK = 15, PT_KERNEL_INTERPRETER = 16, PT_KERNEL_PARK = 32, PT_KERNEL_COUNTING = 64, PT_KERNEL_TEXTURED = 128,
-       PT_KERNEL_FORK = 256 /* idle lanes take the refracted subtrees busy lanes offer (LDS queue, ballot / popcount ranks) */ };
+       PT_KERNEL_FORK = 256 /* idle lanes take the refracted subtrees busy lanes offer (LDS queue, ballot / popcount ranks) */,
+       PT_KERNEL_CHAIN = 512 /* the straight-line kernel with a loop over the depth: every reflective material of the scene is opaque */ };
 
 int pt_abi_version(void);
 int pt_device_count(void);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libportrayer_hip.so")
 TRAVERSE_FLAT, TRAVERSE_KD, TRAVERSE_HIER = 1, 2, 3
 SAMPLE_CENTRE, SAMPLE_RNG = 0, 1
 # pt_stats.kernel_variant (ABI 6): low four bits = waves per SIMD
-KERNEL_WAVES_MASK, KERNEL_INTERPRETER, KERNEL_PARK, KERNEL_COUNTING, KERNEL_TEXTURED, KERNEL_FORK = 15, 16, 32, 64, 128, 256
+KERNEL_WAVES_MASK, KERNEL_INTERPRETER, KERNEL_PARK, KERNEL_COUNTING, KERNEL_TEXTURED, KERNEL_FORK, KERNEL_CHAIN = 15, 16, 32, 64, 128, 256, 512
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -181,6 +181,7 @@ struct pt_context {
     PtBuf spill, stack_spill, accum, bg, rgb, linear, misc;  // misc: work counter + overflow flag (8 B), PtCounters at +256
     bool needs_spill = false;  // some material is reflective (recursion frames) or the scene has more than 32 lights
     bool spawns = false;       // some material is reflective: hits spawn rays, so the cost of a pixel varies by orders of magnitude
+    bool one_ray = false;      // ... and every reflective material is opaque (no index of refraction): a hit spawns at most one ray, the recursion is a chain
     bool forkable = false;     // ... and no hit draws random numbers after the jitter (no area light, no glossy material): refracted subtrees may be walked by other lanes
     uint32_t launch_seq = 0;   // PtRenderArgs::launch_nonce
     bool four_waves = false;   // traversal-heavy scene without reflective materials, flat_scene / hierarchical semantics: a kernel compiled for more than 3 waves per SIMD
@@ -687,6 +688,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
             if (!empty) draws = true;
         }
         c->forkable = c->spawns && dielectric && !draws && s->n_lights <= PT_LIGHT_ROUND;
+        c->one_ray = c->spawns && !dielectric;
     }
     if ((rc = pt_upload(c, c->materials, mats)) || (rc = pt_upload(c, c->lights, lights))) return rc;
 
@@ -941,9 +943,12 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     if (const char* e = getenv("PORTRAYER_FORK")) fork = c->forkable && a.park_slots && atoi(e) > 0;
     if (c->launch_seq == 0) c->launch_seq = (uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u;  // a different starting point in every context
     a.launch_nonce = ++c->launch_seq;
-    if (c->spawns) a.run_variant = a.park_slots ? (fork ? PT_RUN_INTERP_FORK : PT_RUN_INTERP_PARK) : PT_RUN_INTERP;
+    bool chain = c->one_ray;
+    if (const char* e = getenv("PORTRAYER_CHAIN")) chain = chain && atoi(e) > 0;  // 0: the interpreter kernel also for scenes whose recursion is a chain (A/B runs, tests)
+    if (c->spawns) a.run_variant = (chain && a.park_slots) ? PT_RUN_CHAIN : (a.park_slots ? (fork ? PT_RUN_INTERP_FORK : PT_RUN_INTERP_PARK) : PT_RUN_INTERP);
     else if (pt_interpreter_forced()) a.run_variant = a.four_waves ? PT_RUN_INTERP4 : PT_RUN_INTERP;
     else a.run_variant = a.four_waves == 5 ? PT_RUN_LINE5 : (a.four_waves ? PT_RUN_LINE4 : PT_RUN_LINE3);
+    if (a.run_variant == PT_RUN_CHAIN) a.park_slots = 0;  // no frame in LDS: the parked colours go straight to the lane's HBM lines
     size_t block_budget = a.four_waves == 5 ? 31 * 1024 : (a.four_waves ? 39 * 1024 : 52 * 1024);  // 3 x 52 KB, 4 x 39 KB or 5 x 31 KB of the CU's 160 KB
     if (const char* e = getenv("PORTRAYER_LDS_BUDGET_KB")) block_budget = (size_t)std::max(16, std::min(160, atoi(e))) * 1024;  // experiment: 80 = two blocks per CU
     const size_t frame_bytes = (size_t)(PT_LDS_FRAME_F64 + a.park_slots * PT_PARK_F64) * PT_BLOCK * 8;
@@ -989,7 +994,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     a.counters = (PtCounters*)((char*)c->misc.p + 256);
     a.work_queues = (unsigned int*)((char*)c->misc.p + 256 + sizeof(PtCounters));
     c->last_mode = (uint32_t)a.scene.mode;
-    c->last_variant = (a.four_waves ? (uint32_t)a.four_waves : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4 || a.run_variant == PT_RUN_LINE5) ? 0u : PT_KERNEL_INTERPRETER) |
+    c->last_variant = (a.four_waves ? (uint32_t)a.four_waves : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4 || a.run_variant == PT_RUN_LINE5 || a.run_variant == PT_RUN_CHAIN) ? 0u : PT_KERNEL_INTERPRETER) | (a.run_variant == PT_RUN_CHAIN ? PT_KERNEL_CHAIN : 0u) |
                       ((a.run_variant == PT_RUN_INTERP_PARK || a.run_variant == PT_RUN_INTERP_FORK) ? PT_KERNEL_PARK : 0u) | (a.run_variant == PT_RUN_INTERP_FORK ? PT_KERNEL_FORK : 0u) | (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
     PT_HIP(c, hipEventRecord(c->ev0, stream));

@@ -320,6 +320,7 @@ static hipError_t pt_launch_kernel(Kernel kernel, size_t lds, const PtRenderArgs
 //                                        recursion frame in HBM / the youngest in LDS; 3 waves per SIMD
 //   PT_RUN_INTERP_FORK                   PT_RUN_INTERP_PARK + fork / join: idle lanes take the refracted subtrees busy lanes offer (pt_shade.h)
 //   PT_RUN_LINE3 / PT_RUN_LINE4 / _LINE5 the straight-line kernel of pt_render_simple.h (hits spawn nothing), 3 / 4 / 5 waves per SIMD
+//   PT_RUN_CHAIN                         the straight-line kernel with a loop over the depth: scenes whose reflective materials are all opaque (3 waves)
 //   PT_RUN_INTERP4                       -DPT_KEEP_INTERP builds only: the interpreter at 4 waves per SIMD on a scene without reflective
 //                                        materials (what round 2 timed), for A/B runs against the straight-line kernel
 template <int MODE, bool STATS, bool TEX>
@@ -334,6 +335,7 @@ static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_
         if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 2>, lds, a, n_cu, stream, grid_out, launch);
         return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
 #endif
+    case PT_RUN_CHAIN: return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 3, true>, lds, a, n_cu, stream, grid_out, launch);
     case PT_RUN_LINE5:  // mesh-free scenes in the flat_scene / hierarchical semantics: 96 registers, 5 waves per SIMD
         if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>, lds, a, n_cu, stream, grid_out, launch);
         [[fallthrough]];

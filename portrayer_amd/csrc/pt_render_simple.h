@@ -85,7 +85,15 @@ PT_HD uint32_t* pt_fork_queue(const PtRenderArgs& a, uint32_t* lds) {
     return lds + (size_t)wave * a.stack_lds_cap * 64;
 }
 
-template <int MODE, bool STATS, bool TEX, int WAVES>
+// CHAIN (round 3): scenes whose reflective materials are all OPAQUE (reflectivity > 0, no index of refraction - the mirror scene,
+// glossy metal). Their recursion (material.rs:216-243, :312-316) is a chain, not a tree: every hit spawns at most ONE ray, so the
+// samples of a work item still go through the same sequence of ray kinds - bounce by bounce - and the straight line only needs a
+// loop over the depth: trace, shade (shadow rays as above), and where the material reflects, park {colour so far, reflectivity} in the
+// lane's HBM line of that depth and go on with the reflected ray (glossy: its two draws follow the area lights' in the sampling
+// contract's order, which is this loop's order). A chain that ends - background, a matte surface, depth 10 - is folded back at once,
+// innermost first: value = colour_k + value * reflectivity_k, exactly the reference's `color += reflectivity * reflected_color`.
+// Lanes whose chains have ended idle until the wavefront's longest chain has; no interpreter, no stage word, no frame in LDS.
+template <int MODE, bool STATS, bool TEX, int WAVES, bool CHAIN = false>
 __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRenderArgs a) {
     constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH;
     extern __shared__ uint32_t pt_lds[];
@@ -102,7 +110,7 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
     PtFrameRef fr;
     fr.lds = reinterpret_cast<double*>(pt_lds + (size_t)a.stack_lds_cap * PT_BLOCK) + threadIdx.x;
     fr.park = fr.lds;
-    fr.spill = nullptr;
+    fr.spill = CHAIN ? a.spill + (size_t)lane_global * (PT_SPILL_DEPTHS * PT_SPILL_STRIDE) : nullptr;
     fr.n_lanes = a.n_lanes;
 
     PtCounters cnt;
@@ -138,8 +146,14 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
             if (w == 0xFFFFFFFFu) break;
         }
 
-#ifdef PT_CYCLES
+#ifdef PT_CYCLES  // sections of an item outside the walks: diag[3] primary ray, diag[4] surface of the hit, diag[6] light + shadow ray set-up, diag[7] light term
         const unsigned long long cyc_item0 = __builtin_readcyclecounter();
+        unsigned long long sec_t0 = cyc_item0;
+#define PT_SEC_SKIP() sec_t0 = __builtin_readcyclecounter()
+#define PT_SEC_END(k) do { if (STATS && lane == 0) cnt.diag[k] += __builtin_readcyclecounter() - sec_t0; sec_t0 = __builtin_readcyclecounter(); } while (0)
+#else
+#define PT_SEC_SKIP() do { } while (0)
+#define PT_SEC_END(k) do { } while (0)
 #endif
         // ---- the primary ray of this lane's sample (render.rs:36-41, camera.rs:48-84)
         uint32_t x, y;
@@ -160,14 +174,21 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                 if (STATS) cnt.primary++;
             }
         }
+        bool live = mine;     // the lane's chain of rays goes on (without CHAIN: one round)
+        uint32_t draw = 2;    // the two jitter draws came first. CHAIN: per lane (which lanes draw depends on what their rays hit) ...
+        uint32_t udraw = 2;   // ... otherwise the same for every lane: kept where the compiler can see that it is wave-uniform
+        for (int depth = 0; CHAIN ? __any(live) : depth == 0; depth++) {
         PtHit hit;
         hit.t = INFINITY; hit.node = PT_NO_HIT; hit.sub = 0;
-        pt_trace_wave<MODE, STATS>(a, ray, mine, false, hit, stk, pt_lds, &cnt);
+        PT_SEC_END(3);
+        pt_trace_wave<MODE, STATS>(a, ray, live, false, hit, stk, pt_lds, &cnt);
+        PT_SEC_SKIP();
 
-        // ---- ray.rs:139-148: the background where nothing was hit, else Material::hit_color (material.rs:91-243, never its recursive part)
-        const bool shaded = mine && hit.node != PT_NO_HIT;
-        PtVec3 value = pt_v3(0.0, 0.0, 0.0);
-        if (mine && !shaded) value = pt_background(a, x, y);
+        // ---- ray.rs:139-148: the background where nothing was hit, else Material::hit_color (material.rs:91-243)
+        const bool shaded = live && hit.node != PT_NO_HIT;
+        bool ended = live && !shaded;  // this lane's chain ends in this round: `value` is set, the parked colours get folded in
+        PtVec3 value = pt_v3(0.0, 0.0, 0.0);  // (not kept in registers across the rounds: a finished chain's colour goes to the lane's LDS column at once)
+        if (ended) value = pt_background(a, x, y);
         if (__any(shaded)) {
             uint32_t mat = 0, ftag = 0;
             PtRay sray;  // o = the hit point for every light; d = the direction to the light being tested
@@ -184,7 +205,7 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                 if (TEX && (ftag & PT_FS_TEXEL)) kd = pt_v3(sc.srgb_lut[ftag & 255u], sc.srgb_lut[(ftag >> 8) & 255u], sc.srgb_lut[(ftag >> 16) & 255u]);
                 color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * kd;  // material.rs:148
             }
-            uint32_t draw = 2;  // the two jitter draws came first
+            PT_SEC_END(4);
             for (uint32_t li = 0; li < sc.n_lights; li++) {  // material.rs:149-210, one light after the other
                 const double* light = sc.lights + 15 * (size_t)li;
                 double lp[4], la[2], lb[4];  // position (+ colour.x), area_a.xy, area_a.z + area_b
@@ -201,19 +222,23 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                         uint32_t x2, y2;
                         pt_item_lane(a, w, lane, &it, &x2, &y2);
                         const uint64_t key = pt_rng_key(a.seed, (uint64_t)y * a.width + x);
-                        double a_coord = 2.0 * pt_rng_draw(key, it.sample, draw) - 1.0;
-                        double b_coord = 2.0 * pt_rng_draw(key, it.sample, draw + 1) - 1.0;
+                        const uint32_t d0 = CHAIN ? draw : udraw;
+                        double a_coord = 2.0 * pt_rng_draw(key, it.sample, d0) - 1.0;
+                        double b_coord = 2.0 * pt_rng_draw(key, it.sample, d0 + 1) - 1.0;
                         lpos = lpos + (aa * a_coord + ab * b_coord);
+                        if (CHAIN) draw += 2;
                     }
                     PtVec3 hit_to_light = lpos - sray.o;
                     light_dist = pt_length(hit_to_light);
                     sray.d = hit_to_light / light_dist;
                     if (STATS) cnt.shadow++;
                 }
-                if (area) draw += 2;
+                if (area) udraw += 2;
                 PtHit sh;
                 sh.t = INFINITY; sh.node = PT_NO_HIT; sh.sub = 0;
+                PT_SEC_END(6);
                 pt_trace_wave<MODE, STATS>(a, sray, shaded, true, sh, stk, pt_lds, &cnt);  // material.rs:174-179 only asks whether anything is in the way
+                PT_SEC_SKIP();
                 if (shaded && sh.node == PT_NO_HIT) {
                     double lc[2], lf[4];  // colour.xy, colour.z + falloff
                     pt_sload_f64<2>(light + 3, lc);
@@ -223,10 +248,48 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                     if (TEX && (ftag & PT_FS_TEXEL)) kd = pt_v3(sc.srgb_lut[ftag & 255u], sc.srgb_lut[(ftag >> 8) & 255u], sc.srgb_lut[(ftag >> 16) & 255u]);
                     color = color + pt_light_term(pt_v3(lc[0], lc[1], lf[0]), pt_v3(lf[1], lf[2], lf[3]), sray.d, light_dist, fr.l3(PT_L_N), fr.l3(PT_L_D), kd, ks, m[6]);
                 }
+                PT_SEC_END(7);
             }
-            if (shaded) value = color;
+            if (shaded) {
+                const double* m = sc.materials + 10 * (size_t)mat;
+                const double reflectivity = m[7], glossy = m[8];
+                if (!CHAIN || !(reflectivity > 0.0)) {  // material.rs:216: nothing is reflected
+                    value = color; ended = true;
+                } else if (depth + 1 > PT_MAX_DEPTH) {  // the reflected ray would be a depth-11 ray: its colour is the background (material.rs:102-104), not traced
+                    if (STATS) cnt.depth11_skipped++;
+                    value = color + pt_background(a, x, y) * reflectivity;  // material.rs:312-316
+                    ended = true;
+                } else {
+                    const PtVec3 ray_dir = fr.l3(PT_L_D), N = fr.l3(PT_L_N);
+                    PtVec3 reflect_dir = ray_dir - (N * 2.0) * pt_dot(ray_dir, N);  // material.rs:218
+                    if (glossy > 0.0) {  // material.rs:221-239 (not renormalised: quirk Q5)
+                        PtVec3 off = (fabs(reflect_dir.x) < PT_EPSILON && fabs(reflect_dir.y) < PT_EPSILON) ? reflect_dir + pt_v3(0.0, 0.1, 0.0) : reflect_dir + pt_v3(0.0, 0.0, 0.1);
+                        PtVec3 u_basis = pt_cross(reflect_dir, off);
+                        PtVec3 v_basis = pt_cross(reflect_dir, u_basis);
+                        PtItemLane it;
+                        uint32_t x2, y2;
+                        pt_item_lane(a, w, lane, &it, &x2, &y2);
+                        const uint64_t key = pt_rng_key(a.seed, (uint64_t)y * a.width + x);
+                        double u_coord = -glossy / 2.0 + pt_rng_draw(key, it.sample, draw) * glossy;
+                        double v_coord = -glossy / 2.0 + pt_rng_draw(key, it.sample, draw + 1) * glossy;
+                        draw += 2;
+                        reflect_dir = reflect_dir + (u_basis * u_coord + v_basis * v_coord);
+                    }
+                    double* line = fr.spill + (size_t)depth * PT_SPILL_STRIDE;  // parked until the chain ends: colour so far, reflectivity
+                    line[0] = color.x; line[1] = color.y; line[2] = color.z; line[3] = reflectivity;
+                    ray.o = sray.o; ray.d = reflect_dir;
+                    if (STATS) cnt.reflect++;
+                }
+            }
         }
-        if (mine) fr.set_l3(PT_L_VALUE, value);
+        if (CHAIN && ended) {  // fold the parked colours back, innermost first (material.rs:312-316 at every level)
+            for (int k = depth - 1; k >= 0; k--) {
+                const double* line = fr.spill + (size_t)k * PT_SPILL_STRIDE;
+                value = pt_v3(line[0], line[1], line[2]) + value * line[3];
+            }
+        }
+        if (ended) { fr.set_l3(PT_L_VALUE, value); live = false; }
+        }
 
         // render.rs:36-43 under the summation contract: the chunk's samples in ascending order, added by the lane of the chunk's
         // first sample from its neighbours' LDS columns (same wavefront: program order suffices).

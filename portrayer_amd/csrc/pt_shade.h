@@ -101,7 +101,7 @@ inline bool pt_interpreter_forced() {
 #endif
 }
 
-enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4, PT_RUN_INTERP_FORK = 5, PT_RUN_LINE5 = 6 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
+enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4, PT_RUN_INTERP_FORK = 5, PT_RUN_LINE5 = 6, PT_RUN_CHAIN = 7 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
 
 struct PtRenderArgs {
     PtSceneView scene;

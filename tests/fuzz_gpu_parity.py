@@ -2,7 +2,7 @@
 """Fuzz parity run (not collected by pytest; run on the GPU box):
    python tests/fuzz_gpu_parity.py <first seed> <count> [width height [samples]]
 Random scenes (tests/test_gpu_render_parity.random_scene) with extreme scales / near-degenerate
-transforms mixed in, textured scenes, and mesh-free scenes without reflection (the wave-uniform walk); FLAT, KD and HIER, GPU vs oracle: reports every pixel that differs."""
+transforms mixed in, textured scenes, mesh-free scenes without reflection (the wave-uniform walk), scenes with mirrors but no glass (the chain kernel); FLAT, KD and HIER, GPU vs oracle: reports every pixel that differs."""
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -52,7 +52,8 @@ def main():
     tex_edge = 0
     for seed in range(first, first + count):
         from test_gpu_textures import textured_scene  # random texels, normal maps, uv transforms on every primitive kind
-        for kind, make in (("random", random_scene), ("extreme", extreme_scene), ("textured", textured_scene), ("analytic", analytic_scene)):
+        for kind, make in (("random", random_scene), ("extreme", extreme_scene), ("textured", textured_scene), ("analytic", analytic_scene),
+                           ("mirrors", lambda sd: random_scene(sd, dielectric=False))):  # mirrors / glossy, nothing refracts: the straight-line kernel's depth loop
             scene, cam = make(seed)
             ps = O.pack(scene)
             hs = host_glue.host_scene(scene)
@@ -77,7 +78,7 @@ def main():
                     print(f"MISMATCH seed {seed} {kind} {mode}: {int(bad.sum())} pixels, rays_equal={rays_equal}, first {np.argwhere(bad)[:4].tolist()}, "
                           f"kd_plane_miss gpu {st['kd_plane_miss']} oracle {ref.stats['kd_plane_miss']}", flush=True)
                 r.close()
-    print(f"fuzz done: seeds {first}..{first + count - 1} ({12 * count} renders, {w}x{h}x{samples}), {bad_total} differing pixels in total ({tex_edge} texel-edge pixels in textured scenes tolerated)")
+    print(f"fuzz done: seeds {first}..{first + count - 1} ({15 * count} renders, {w}x{h}x{samples}), {bad_total} differing pixels in total ({tex_edge} texel-edge pixels in textured scenes tolerated)")
 
 
 if __name__ == "__main__":

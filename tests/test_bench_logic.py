@@ -32,8 +32,9 @@ def test_committed_profiles_exist_and_are_complete():
 
 
 def test_kernel_name_follows_pt_stats(bench):
-    assert bench.kernel_name({"kernel_mode": 3, "kernel_variant": 4}) == "void pt_render_simple_kernel<3, false, false, 4>(PtRenderArgs)"
-    assert bench.kernel_name({"kernel_mode": 1, "kernel_variant": 3 | 128}) == "void pt_render_simple_kernel<1, false, true, 3>(PtRenderArgs)"
+    assert bench.kernel_name({"kernel_mode": 3, "kernel_variant": 4}) == "void pt_render_simple_kernel<3, false, false, 4, false>(PtRenderArgs)"
+    assert bench.kernel_name({"kernel_mode": 1, "kernel_variant": 3 | 128}) == "void pt_render_simple_kernel<1, false, true, 3, false>(PtRenderArgs)"
+    assert bench.kernel_name({"kernel_mode": 1, "kernel_variant": 3 | 512}) == "void pt_render_simple_kernel<1, false, false, 3, true>(PtRenderArgs)"
     assert bench.kernel_name({"kernel_mode": 4, "kernel_variant": 3 | 16 | 32 | 128}) == "void pt_render_kernel<4, false, true, 1>(PtRenderArgs)"
     assert bench.kernel_name({"kernel_mode": 4, "kernel_variant": 3 | 16 | 32 | 128 | 256}) == "void pt_render_kernel<4, false, true, 3>(PtRenderArgs)"
     assert bench.kernel_name({"kernel_mode": 3, "kernel_variant": 4 | 16}) == "void pt_render_kernel<3, false, false, 2>(PtRenderArgs)"
@@ -46,7 +47,7 @@ def test_a_profile_is_quoted_only_for_the_kernel_that_runs(bench):
         base = key.rsplit("/waves", 1)[0]
         assert bench.measured_profile(base, e["kernel"]) is not None
         assert bench.measured_profile(base, "void some_other_kernel<1>(PtRenderArgs)") is None
-    assert bench.measured_profile("no-such-workload/flat/gpus1", "void pt_render_simple_kernel<3, false, false, 4>(PtRenderArgs)") is None
+    assert bench.measured_profile("no-such-workload/flat/gpus1", "void pt_render_simple_kernel<3, false, false, 4, false>(PtRenderArgs)") is None
 
 
 def test_roofline_block_shape(bench):
@@ -57,13 +58,13 @@ def test_roofline_block_shape(bench):
     assert r["bound"] == "valu" and r["peak"] == 39.3 and r["traffic"] is None
     assert r["achieved"] == pytest.approx((f64 + 0.5 * f32) / 0.01 / 1e12) and r["frac"] == pytest.approx(r["achieved"] / 39.3)
     assert r["hbm"]["needed_bytes"] == 5.0e8 and r["hbm"]["measured_bytes"] is None and r["hbm"]["waste_ratio"] is None and "no PMC profile" in r["hbm"]["profile"]
-    assert r["algorithmic"]["GBps"] == pytest.approx(100.0) and r["kernel"].startswith("void pt_render_simple_kernel<3, false, false, 4>")
+    assert r["algorithmic"]["GBps"] == pytest.approx(100.0) and r["kernel"].startswith("void pt_render_simple_kernel<3, false, false, 4, false>")
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     for key, e in t.items():
         if "/waves" in key or "pt_render_simple_kernel<" not in e["kernel"]:
             continue
-        mode, tex, waves = e["kernel"].split("<")[1].split(">")[0].replace(" ", "").split(",")[0::2] + [None]
-        st = dict(counts, kernel_mode=int(mode), kernel_variant=int(e["kernel"].split(",")[-1].split(">")[0]))
+        mode, _, tex, waves, chain = e["kernel"].split("<")[1].split(">")[0].replace(" ", "").split(",")  # <MODE, STATS, TEX, WAVES, CHAIN>
+        st = dict(counts, kernel_mode=int(mode), kernel_variant=int(waves) | (128 if tex == "true" else 0) | (512 if chain == "true" else 0))
         r = bench.roofline_block(key, True, st, 1.0e9, 0.0175, 6000.0, counts, counts, 300, 3, "flat", 5.0e8)
         assert r["traffic"] == e["hbm_bytes_per_launch"] and r["hbm"]["waste_ratio"] == pytest.approx(r["traffic"] / 5.0e8)
         assert r["hbm"]["GBps"] == pytest.approx(r["traffic"] / 0.0175 / 1e9)

@@ -139,7 +139,7 @@ def test_gpu_render_matches_reference_golden(host, H, name, png, mode, exact_min
 # ---------------------------------------------------------------------------------------------------
 # random scenes: every primitive, nested instancing, mirrors, dielectrics, glossy, area lights
 # ---------------------------------------------------------------------------------------------------
-def random_scene(seed, with_mesh=True):
+def random_scene(seed, with_mesh=True, dielectric=True):
     rng = np.random.default_rng(seed)
     from example_scenes import load_mesh
     mats = []
@@ -151,7 +151,9 @@ def random_scene(seed, with_mesh=True):
             m.reflectivity = float(rng.uniform(0.2, 1.0))
         if kind == 3:
             m.reflectivity = 0.8; m.glossy_side_length = float(rng.uniform(0.05, 0.5))
-        if kind == 4:
+        if kind == 4 and not dielectric:
+            m.reflectivity = 1.0  # a perfect mirror instead of the glass: chains that only the depth limit ends
+        elif kind == 4:
             m.reflectivity = 0.9; m.refraction_index = float(rng.choice([1.33, 1.51, 2.42]))
         mats.append(m)
     prims = [Sphere, Cube, Plane, Cylinder, Cone]
@@ -408,6 +410,37 @@ def _render_hier(oracle, host, H, scene, cam, w, h, **kw):
     ref = oracle.render(scene, cam, w, h, mode=oracle.MODE_HIER, **({"samples": kw["samples"], "seed": kw["seed"], "jitter": oracle.JITTER_RNG} if kw else {}))
     r.close()
     return rgb, linear, st, ref
+
+
+@pytest.mark.parametrize("mode", ["flat", "kd", "hier"])
+@pytest.mark.parametrize("seed", range(4))
+def test_chain_kernel_matches_interpreter_and_oracle(oracle, host, H, monkeypatch, seed, mode):
+    """Scenes whose reflective materials are all opaque (mirrors, glossy metal; no index of refraction) run the straight-line
+    kernel with a loop over the depth (pt_render_simple.h, CHAIN) instead of the interpreter; PORTRAYER_CHAIN=0 keeps the
+    interpreter. Same image, same f64 means, same ray counts - and the oracle's: perfect mirrors facing each other (chains the
+    depth limit ends, material.rs:102-104), glossy draws after area-light draws, meshes, instancing."""
+    scene, cam = random_scene(100 + seed, dielectric=False)
+    tr, om = {"flat": (H.TRAVERSE_FLAT, oracle.MODE_FLAT), "kd": (H.TRAVERSE_KD, oracle.MODE_KD), "hier": (H.TRAVERSE_HIER, oracle.MODE_HIER)}[mode]
+    w, h, samples = 128, 96, 3
+    bg = default_background(w, h)
+    r = host.Renderer(host_glue.host_scene(scene), tr, kd_depth=6)
+    kw = dict(samples=samples, seed=seed, sample_mode=H.SAMPLE_RNG)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, bg, stats=True, **kw)
+    fast, fast_linear, st1 = r.render(host_glue.cam10(cam), w, h, bg, **kw)  # the non-counting instantiation
+    assert st["kernel_variant"] & H.KERNEL_CHAIN and st1["kernel_variant"] & H.KERNEL_CHAIN
+    monkeypatch.setenv("PORTRAYER_CHAIN", "0")
+    old, old_linear, st0 = r.render(host_glue.cam10(cam), w, h, bg, stats=True, **kw)
+    r.close()
+    assert not st0["kernel_variant"] & H.KERNEL_CHAIN and st0["kernel_variant"] & H.KERNEL_INTERPRETER
+    assert np.array_equal(rgb, old) and np.array_equal(linear, old_linear), "the chain kernel and the interpreter disagree"
+    assert np.array_equal(fast, rgb) and np.array_equal(fast_linear, linear)
+    ref = oracle.render(oracle.pack(scene), cam, w, h, samples=samples, seed=seed, jitter=oracle.JITTER_RNG, mode=om, kd_depth=6)
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert st[k] == st0[k] == ref.stats[k], k
+    assert st["depth11_skipped"] == st0["depth11_skipped"] == ref.stats["depth11"]
+    assert st["reflect"] > 0 and st["refract"] == 0
+    assert np.array_equal(rgb, ref.rgb)
+    assert_ulp(linear, ref.linear, 0)
 
 
 @pytest.mark.parametrize("name", ["water-glass", "transmission-refraction", "hier", "instance", "entering-the-mirror-dimension", "macho-cows", "glossy-reflection"])
