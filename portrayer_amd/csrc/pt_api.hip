@@ -870,6 +870,10 @@ static void pt_fill_work(const pt_render_params* p, PtRenderArgs* a) {
     if (const char* e = getenv("PORTRAYER_LANE_CHUNKS")) { uint32_t v = (uint32_t)atoi(e); if (k == PT_SAMPLE_CHUNK && (v == 1 || v == 2 || v == 4 || v == 8)) cc = v; }
     a->lane_chunks = cc;
     a->n_items = (a->n_slots / 64) * ((a->n_chunks + cc - 1) / cc) * (k * cc);
+    for (a->k_log2 = 0; (1u << a->k_log2) < k; a->k_log2++) { }
+    for (a->c_log2 = 0; (1u << a->c_log2) < cc; a->c_log2++) { }
+    a->div_groups = pt_fastdiv_make((a->n_chunks + cc - 1) / cc);
+    a->div_tiles_x = pt_fastdiv_make(empty ? 1u : (p->slice.x1 - p->slice.x0 + 1u + 7u) / 8u);
 }
 
 static int pt_fill_args(pt_context* c, const pt_camera* cam, const pt_render_params* p, PtRenderArgs* a) {
@@ -900,9 +904,15 @@ extern "C" int pt_test_work_items(const pt_render_params* p, uint32_t* sample_co
     }
     for (uint32_t w = 0; w < a.n_items; w++)
         for (uint32_t lane = 0; lane < 64; lane++) {
-            PtItemLane it;
-            uint32_t x, y;
-            if (!pt_item_lane(a, w, lane, &it, &x, &y)) continue;
+            PtItemLane it, it_k;
+            uint32_t x, y, x_k, y_k;
+            const bool mine = pt_item_lane(a, w, lane, &it, &x, &y);
+            // what the render kernels actually run (shifts + multiply-high divisions) must agree in every field
+            const bool mine_k = pt_item_lane_fast(a, w, lane, &it_k, &x_k, &y_k);
+            if (mine != mine_k || it.slot != it_k.slot || it.chunk != it_k.chunk || it.sample != it_k.sample || it.first != it_k.first || it.count != it_k.count ||
+                (mine && (x != x_k || y != y_k)))
+                return PT_ERR_TRAVERSAL;
+            if (!mine) continue;
             if (x >= p->width || y >= p->height) return PT_ERR_TRAVERSAL;  // would write outside the image
             const size_t px = (size_t)y * p->width + x;
             sample_count[px]++;

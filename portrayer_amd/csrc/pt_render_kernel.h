@@ -59,7 +59,8 @@ __host__ __device__ inline size_t pt_render_lds_bytes(int stack_lds_cap, bool te
 #include "pt_render_simple.h"
 
 template <int MODE, bool STATS, bool TEX, int VAR>
-__global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(PtRenderArgs a) {
+__global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(PtRenderArgs a0) {
+    const PtRenderArgs& a = a0;
     constexpr int PARK = (VAR == 1 || VAR == 3) ? 1 : 0;
     constexpr bool FORK = VAR == 3;  // idle lanes take the refracted subtrees busy lanes offer (pt_shade.h: fork / join)
     extern __shared__ uint32_t pt_lds[];
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
         {
             PtItemLane it0;
             uint32_t x0, y0;
-            const bool mine0 = pt_item_lane(a, w, lane, &it0, &x0, &y0);
+            const bool mine0 = pt_item_lane_fast(a, w, lane, &it0, &x0, &y0);
             L.item = w;
             L.x = x0; L.y = y0;
             L.stage = mine0 ? PT_ST_NEW_SAMPLE : PT_ST_DONE;
@@ -151,6 +152,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 #endif
 #ifdef PT_CYCLES
             const unsigned long long cyc_a = __builtin_readcyclecounter();
+#endif
+#ifndef PT_NO_ARGS_AGAIN
+            const PtRenderArgs& a = pt_args_again(a0);  // what the interpreter and this pass's walk need of the arguments is fetched now, not kept from the top of the kernel on (pt_render_simple.h)
 #endif
             if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH, PARK, FORK>(a, L, hit, fr, &cnt);
             if (FORK) {
@@ -242,7 +246,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 #endif
         PtItemLane it;
         uint32_t x_again, y_again;
-        const bool mine = pt_item_lane(a, w_again, lane, &it, &x_again, &y_again);
+        const bool mine = pt_item_lane_fast(a, w_again, lane, &it, &x_again, &y_again);
         if (mine && it.first) {
             PtVec3 sum;
             if (FORK) {  // finished samples wait in the lanes' result slots in HBM (the LDS frames were reused by taken tasks)

@@ -36,12 +36,30 @@ PT_HD void pt_sload_f64(const double* p, double* out) {
 #endif
 }
 
+// The kernel's argument block seen AGAIN through a pointer the compiler cannot trace back to the kernarg segment: what is read
+// through it is fetched (scalar loads, constant cache) where it is used instead of being kept in scalar registers from the top of
+// the kernel on. The straight-line kernels keep ~200 wave-uniform values alive (scene pointers, camera, item geometry); what does
+// not fit the 106 scalar registers is spilled into lanes of a vector register and comes back one v_readlane each - VALU issue slots,
+// 180 of them per work item before this (38 for the camera alone, at the start of every item).
+PT_HD const PtRenderArgs& pt_args_again(const PtRenderArgs& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) PtRenderArgs* ka = (const __attribute__((address_space(4))) PtRenderArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *(const PtRenderArgs*)ka;
+#else
+    return a;
+#endif
+}
+
 // One ray kind for the whole wavefront: `tracing` lanes carry `ray`; result in `hit` (untouched for the other lanes).
 template <int MODE, bool STATS>
 PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, bool any, PtHit& hit, const PtStackSpill& stk, uint32_t* lds, PtCounters* cnt) {
 #ifdef PT_CYCLES  // profiles/cycles.sh: wave cycles inside the walks -> diag[0], calls -> diag[1]
     const unsigned long long cyc_t0 = __builtin_readcyclecounter();
     struct CycEnd { unsigned long long t0; PtCounters* c; __device__ ~CycEnd() { if (STATS && (threadIdx.x & 63u) == 0) { c->diag[0] += __builtin_readcyclecounter() - t0; c->diag[1]++; } } } cyc_end{cyc_t0, cnt};
+#endif
+#if defined(PT_ABLATE) && (PT_ABLATE == 5 || PT_ABLATE == 6)  // measurement builds only (profiles/light_slope.py): 5 = no shadow walks (nothing is ever in the way), 6 = no walks at all
+    if (any || PT_ABLATE == 6) return;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t wave = threadIdx.x >> 6;
@@ -94,9 +112,10 @@ PT_HD uint32_t* pt_fork_queue(const PtRenderArgs& a, uint32_t* lds) {
 // innermost first: value = colour_k + value * reflectivity_k, exactly the reference's `color += reflectivity * reflected_color`.
 // Lanes whose chains have ended idle until the wavefront's longest chain has; no interpreter, no stage word, no frame in LDS.
 template <int MODE, bool STATS, bool TEX, int WAVES, bool CHAIN = false>
-__global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRenderArgs a) {
+__global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRenderArgs a0) {
     constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH;
     extern __shared__ uint32_t pt_lds[];
+    const PtRenderArgs& a = a0;
     const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     const PtSceneView& sc = a.scene;
@@ -155,6 +174,10 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
 #define PT_SEC_SKIP() do { } while (0)
 #define PT_SEC_END(k) do { } while (0)
 #endif
+#ifndef PT_NO_ARGS_AGAIN  // (shadows the kernel's own view of its arguments for the rest of the item; the k-d semantics measured 1.5 % better off without)
+        const PtRenderArgs& a = (MODE == PT_MODE_KD || MODE == PT_MODE_KD_NOMESH) ? a0 : pt_args_again(a0);
+        const PtSceneView& sc = a.scene;
+#endif
         // ---- the primary ray of this lane's sample (render.rs:36-41, camera.rs:48-84)
         uint32_t x, y;
         bool mine;
@@ -162,7 +185,7 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
         ray.o = ray.d = pt_v3(0.0, 0.0, 0.0);
         {
             PtItemLane it;
-            mine = pt_item_lane(a, w, lane, &it, &x, &y);
+            mine = pt_item_lane_fast(a, w, lane, &it, &x, &y);
             if (mine) {
                 double jx = 0.5, jy = 0.5;
                 if (a.jitter_mode == PT_JITTER_RNG) {  // render.rs:38-39: x drawn before y
@@ -220,7 +243,7 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                     if (area) {  // light.rs:62-70, :87-90
                         PtItemLane it;
                         uint32_t x2, y2;
-                        pt_item_lane(a, w, lane, &it, &x2, &y2);
+                        pt_item_lane_fast(a, w, lane, &it, &x2, &y2);
                         const uint64_t key = pt_rng_key(a.seed, (uint64_t)y * a.width + x);
                         const uint32_t d0 = CHAIN ? draw : udraw;
                         double a_coord = 2.0 * pt_rng_draw(key, it.sample, d0) - 1.0;
@@ -268,7 +291,7 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                         PtVec3 v_basis = pt_cross(reflect_dir, u_basis);
                         PtItemLane it;
                         uint32_t x2, y2;
-                        pt_item_lane(a, w, lane, &it, &x2, &y2);
+                        pt_item_lane_fast(a, w, lane, &it, &x2, &y2);
                         const uint64_t key = pt_rng_key(a.seed, (uint64_t)y * a.width + x);
                         double u_coord = -glossy / 2.0 + pt_rng_draw(key, it.sample, draw) * glossy;
                         double v_coord = -glossy / 2.0 + pt_rng_draw(key, it.sample, draw + 1) * glossy;
@@ -299,7 +322,7 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
         {
             PtItemLane it;
             uint32_t x2, y2;
-            const bool mine2 = pt_item_lane(a, w, lane, &it, &x2, &y2);
+            const bool mine2 = pt_item_lane_fast(a, w, lane, &it, &x2, &y2);
             if (mine2 && it.first) {
                 PtVec3 sum = fr.l3(PT_L_VALUE);
                 for (uint32_t k = 1; k < it.count; k++) {

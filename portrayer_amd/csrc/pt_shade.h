@@ -101,6 +101,22 @@ inline bool pt_interpreter_forced() {
 #endif
 }
 
+// Division of a wave-uniform index by a launch constant without a divider: q = (n * magic) >> shift, exact for every n < 2^31
+// (magic = ceil(2^shift / d), shift = 31 + ceil(log2 d): the error of magic / 2^shift is below 2^-31 / d ... n e < 2^shift).
+// The scalar unit has multiply-high and shifts but no division: hipcc turns `w / n_groups` into a float reciprocal on the VECTOR
+// unit, six of them per pt_item_lane call.
+struct PtFastDiv { uint32_t d, magic, shift; };
+PT_HD uint32_t pt_fastdiv(uint32_t n, const PtFastDiv& f) { return (uint32_t)(((uint64_t)n * f.magic) >> f.shift); }
+inline PtFastDiv pt_fastdiv_make(uint32_t d) {
+    PtFastDiv f;
+    f.d = d < 1u ? 1u : d;
+    uint32_t l = 0;
+    while ((1ull << l) < f.d) l++;
+    f.shift = 31u + l;
+    f.magic = (uint32_t)(((1ull << f.shift) + f.d - 1u) / f.d);
+    return f;
+}
+
 enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4, PT_RUN_INTERP_FORK = 5, PT_RUN_LINE5 = 6, PT_RUN_CHAIN = 7 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
 
 struct PtRenderArgs {
@@ -119,6 +135,9 @@ struct PtRenderArgs {
     uint32_t lane_samples;           // K = samples of a chunk that run side by side in a wavefront: 8, or the next power of two >= samples
     uint32_t lane_chunks;            // C = chunks of a pixel that run side by side (1, 2, 4 or 8); a wavefront covers 64 / (K C) pixels
     uint32_t n_items;                // wavefront work items of this launch = own tiles x ceil(n_chunks / C) x (K C)
+    uint32_t k_log2, c_log2;         // K and C are powers of two: their logarithms, for pt_item_lane_fast
+    PtFastDiv div_groups;            // by ceil(n_chunks / C): item -> (local tile, chunk group)
+    PtFastDiv div_tiles_x;           // by the slice's tiles per row: tile -> (row, column)
     double* accum;                   // n_slots x n_chunks x 3: per (tile, chunk, pixel) sum of the chunk's samples
     int32_t compact;                 // 1: rgb is tile-major over own tiles; 0: rgb is the full H x W x 3 image
     uint8_t* rgb;
@@ -244,6 +263,29 @@ PT_HD bool pt_item_lane(const PtRenderArgs& a, uint32_t w, uint32_t lane, PtItem
     return pt_slot_to_pixel(a, it->slot, x, y) && si < it->count;
 }
 
+// The same, the way the render kernels compute it: shifts and masks for the lane part (K, C and so P are powers of two), two
+// multiply-high divisions on the scalar unit for the item part (pt_fill_work prepares them). pt_test_work_items replays every item
+// of a launch through both and fails if they ever differ.
+PT_HD bool pt_item_lane_fast(const PtRenderArgs& a, uint32_t w, uint32_t lane, PtItemLane* it, uint32_t* x, uint32_t* y) {
+    const uint32_t kl = a.k_log2, cl = a.c_log2, parts_l = kl + cl, pl = 6u - parts_l;
+    const uint32_t part = w & ((1u << parts_l) - 1u), g = w >> parts_l;
+    const uint32_t tile_local = pt_fastdiv(g, a.div_groups), group = g - tile_local * a.div_groups.d;
+    const uint32_t si = lane & ((1u << kl) - 1u), ci = (lane >> kl) & ((1u << cl) - 1u), pi = lane >> parts_l;
+    const uint32_t j = pt_tile_order_to_slot((part << pl) + pi);
+    const uint32_t chunk = (group << cl) + ci;
+    it->slot = (tile_local << 6) | j;
+    it->chunk = chunk;
+    it->sample = chunk * PT_SAMPLE_CHUNK + si;
+    it->first = si == 0u;
+    const uint32_t left = chunk < a.n_chunks ? a.samples - chunk * PT_SAMPLE_CHUNK : 0u;
+    it->count = left < (uint32_t)PT_SAMPLE_CHUNK ? left : (uint32_t)PT_SAMPLE_CHUNK;
+    const uint32_t tile = tile_local * a.tile_ranks + a.tile_rank;
+    const uint32_t ty = pt_fastdiv(tile, a.div_tiles_x), tx = tile - ty * a.div_tiles_x.d;
+    const uint32_t px = a.x0 + tx * 8u + (j & 7u), py = a.y0 + ty * 8u + (j >> 3);
+    *x = px; *y = py;
+    return px <= a.x1 && py <= a.y1 && si < it->count;
+}
+
 // The lane's sample index, worked out from the wave-uniform item index where it is needed (the jitter draws at the start of
 // the sample, area-light and glossy draws) instead of being carried through every tree walk in a register that hipcc then
 // spills at the start of every item (measured: 2.3 -> 0.7 GB of scratch writes per 1920x1080x64 frame, +0.5-2 % on most
@@ -258,7 +300,7 @@ PT_HD uint32_t pt_lane_sample(const PtRenderArgs& a, uint32_t item) {
 #endif
     PtItemLane it;
     uint32_t x, y;
-    pt_item_lane(a, item, lane, &it, &x, &y);
+    pt_item_lane_fast(a, item, lane, &it, &x, &y);
     return it.sample;
 }
 
@@ -271,7 +313,7 @@ PT_HD void pt_lane_xy(const PtRenderArgs& a, uint32_t item, uint32_t* x, uint32_
     const uint32_t lane = 0;
 #endif
     PtItemLane it;
-    pt_item_lane(a, item, lane, &it, x, y);
+    pt_item_lane_fast(a, item, lane, &it, x, y);
 }
 #ifdef PT_XY_ON_DEMAND
 #define PT_LANE_XY(a, L, X, Y) uint32_t X, Y; pt_lane_xy(a, (L).item, &X, &Y)
@@ -542,11 +584,25 @@ PT_HD void pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& 
 // falloff = its three attenuation coefficients (light.rs:31-33), light_dir / light_dist as the shadow ray was set up.
 PT_HD PtVec3 pt_light_term(PtVec3 lcol, PtVec3 falloff, PtVec3 light_dir, double light_dist, PtVec3 N, PtVec3 ray_dir, PtVec3 kd, PtVec3 ks,
                            double shininess) {
+#if defined(PT_ABLATE) && PT_ABLATE == 2  // measurement builds only (profiles/light_slope.py): no light term at all
+    return lcol;
+#endif
     double attenuation = falloff.x + falloff.y * light_dist + falloff.z * light_dist * light_dist;  // light.rs:31-33
     double normal_light = fmax(pt_dot(N, light_dir), 0.0);
     PtVec3 diffuse = (kd * lcol) * normal_light;
     PtVec3 specular = pt_v3(0.0, 0.0, 0.0);
+#if defined(PT_ABLATE) && PT_ABLATE == 1  // measurement builds only: no specular term (half vector, pow)
+    if (false) {
+#elif defined(PT_ABLATE) && PT_ABLATE == 3  // measurement builds only: the device library's pow instead of glibc's
     if (ks.x > PT_EPSILON || ks.y > PT_EPSILON || ks.z > PT_EPSILON) {
+        PtVec3 view = -ray_dir;
+        PtVec3 half = pt_normalized(view + light_dir);
+        double nhs = pow(fmax(pt_dot(N, half), 0.0), 4.0 * shininess);
+        specular = (ks * lcol) * nhs;
+    } else if (false) {
+#else
+    if (ks.x > PT_EPSILON || ks.y > PT_EPSILON || ks.z > PT_EPSILON) {
+#endif
         PtVec3 view = -ray_dir;
         PtVec3 half = pt_normalized(view + light_dir);
         double nhs = pt_pow(fmax(pt_dot(N, half), 0.0), 4.0 * shininess);

@@ -911,24 +911,6 @@ PT_HD pt_u32x4 pt_sload4(const void* p) {
 #endif
     return v;
 }
-// -DPT_PREFETCH_CHILDREN (experiment): pull a record's cache line into the scalar cache without waiting for it. The destination
-// register stays allocated until the next pt_sload16_after(), whose s_waitcnt also covers this load.
-PT_HD uint32_t pt_sprefetch(const void* p) {
-    uint32_t v = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(pt_uniform_ptr(p)) : "memory");
-#endif
-    return v;
-}
-PT_HD pt_u32x16 pt_sload16_after(const void* p, uint32_t dep0, uint32_t dep1) {
-    pt_u32x16 v;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pt_uniform_ptr(p)), "s"(dep0), "s"(dep1) : "memory");
-#else
-    v = *static_cast<const pt_u32x16*>(p);
-#endif
-    return v;
-}
 PT_HD double pt_f64_of(uint32_t lo, uint32_t hi) {
     union { double d; uint32_t u[2]; } c;
     c.u[0] = lo; c.u[1] = hi;
