@@ -26,6 +26,8 @@ for r in csv.DictReader(open(f"{dst}/{tag}_kernel_stats.csv")):
         out["kernel"] = r["Name"]; out["kernel_trace_avg_ns"] = float(r["AverageNs"]); out["kernel_trace_calls"] = int(r["Calls"])
 g = lambda k: out[k]["mean_per_launch"]
 ms = out["kernel_trace_avg_ns"] / 1e6
+# lanes_active: thread quad-cycles per vector instruction. An instruction that takes more than one pass (f64 reciprocal / square root, 32-bit integer
+# multiply) counts its lanes once per pass, so the figure is biased upwards (64.7 "of 64" on the chain kernel); single-lane v_readlane / v_writelane pull it down.
 derived = {"lanes_active": g("SQ_THREAD_CYCLES_VALU") / g("SQ_INSTS_VALU"),
            "valu_busy": 4 * g("SQ_ACTIVE_INST_VALU") / (1024 * ms * 1e-3 * 2.4e9),  # SQ_ACTIVE_INST_VALU counts quad-cycles; 1024 SIMDs at 2.4 GHz
            "waiting": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))}

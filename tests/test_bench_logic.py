@@ -27,7 +27,9 @@ def test_committed_profiles_exist_and_are_complete():
         path = e["source"].split(" ")[0]
         assert os.path.exists(os.path.join(ROOT, path)), path
         assert os.path.exists(os.path.join(ROOT, path.replace("_pmc.json", "_kernel_stats.csv")))
-        assert 0 < e["lanes_active"] <= 64 and 0 < e["valu_busy"] <= 1
+        # SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU: thread quad-cycles per vector instruction = lanes active, biased upwards where multi-pass
+        # instructions (f64 reciprocals, 32-bit integer multiplies) are frequent: the chain kernel reads 64.7
+        assert 0 < e["lanes_active"] <= 68 and 0 < e["valu_busy"] <= 1
         assert "pt_render" in e["kernel"] and ", false," in e["kernel"], "the timed kernel, not the counting launch"
 
 
