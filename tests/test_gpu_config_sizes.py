@@ -70,6 +70,9 @@ def test_config_size_render(oracle, host, H, name, w, h, samples, lights, mode):
     assert st["primary"] == w * h * samples
     assert st["shadow"] == lights * st["hits"]
     assert st["stack_overflow"] == 0
+    # the instantiation bench.py times by default: the straight-line kernel - with the loop over the depth for the mirror scene (C4)
+    assert not st["kernel_variant"] & H.KERNEL_INTERPRETER
+    assert bool(st["kernel_variant"] & H.KERNEL_CHAIN) == (name == "entering-the-mirror-dimension")
     # determinism, and the reference's slice API (render.rs:56-66): two half renders into one image == the whole
     again, _ = render(host, H, r, sc, w, h, samples)
     assert np.array_equal(rgb, again)
