@@ -116,6 +116,8 @@ struct PtSceneView {
     const uint32_t* chain_off;  // n_nodes + 1
     const uint32_t* chain;      // graph node indices, root first
     const uint32_t* dfs_rank;   // per flattened node: depth-first order, a node before its children (who wins equal hits)
+    const uint32_t* hier_rec;   // per flattened node 8 words: levels on its path (bits 0-7; 255 = more than 7: use chain_off / chain) | bit 8 + k set where
+                                // level k's three matrices are the identity; then the graph node indices of levels 0..6, root first (pt_trace.h)
     const float* kd_box;     // KD mode: non-null = PtKdNode::box is valid and the walk culls with it (the array itself is a copy kept for tools); else null
     const float* node_box;   // KD mode: per kd_items entry, that node's padded world box as 6 f32 rounded outward (leaf pre-cull in pt_trace_kd); else null
     double kd_extent;  // bounding_box.rs:95-99: squared diagonal of the root bounds

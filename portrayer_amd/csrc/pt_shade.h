@@ -561,9 +561,19 @@ PT_HD void pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& 
     PtVec3 P, Nw;
     if (HIER) {  // scene.rs:100-101, :111-112: every level on the way up applies its own trans / normal_trans
         P = p; Nw = n;
-        for (uint32_t k = sc.chain_off[hit.node + 1]; k-- > sc.chain_off[hit.node];) {
-            P = pt_xform_point(sc.g_fwd + 12 * (size_t)sc.chain[k], P);
-            Nw = pt_xform_dir(sc.g_nrm + 9 * (size_t)sc.chain[k], 3, Nw);
+        const uint32_t* rec = sc.hier_rec + 8 * (size_t)hit.node;  // the node's path in one 32-byte line (pt_api.hip) instead of chain_off -> chain
+        const uint32_t len = rec[0] & 255u;
+        if (len == 255u) {  // more than seven levels
+            for (uint32_t k = sc.chain_off[hit.node + 1]; k-- > sc.chain_off[hit.node];) {
+                P = pt_xform_point(sc.g_fwd + 12 * (size_t)sc.chain[k], P);
+                Nw = pt_xform_dir(sc.g_nrm + 9 * (size_t)sc.chain[k], 3, Nw);
+            }
+        } else {
+            for (uint32_t k = len; k-- > 0u;) {
+                const uint32_t g = rec[1 + k];
+                P = pt_xform_point(sc.g_fwd + 12 * (size_t)g, P);
+                Nw = pt_xform_dir(sc.g_nrm + 9 * (size_t)g, 3, Nw);
+            }
         }
     } else {
         P = pt_xform_point(sc.fwd + 12 * (size_t)hit.node, p);

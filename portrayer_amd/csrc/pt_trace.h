@@ -363,7 +363,13 @@ template <bool HIER>
 PT_HD PtRay pt_node_local_ray(const PtSceneView& sc, uint32_t node, const PtRay& ray) {
     if (!HIER) return pt_ray_to_local(sc.inv + 12 * (size_t)node, ray);
     PtRay r = ray;
-    for (uint32_t k = sc.chain_off[node]; k < sc.chain_off[node + 1]; k++) r = pt_ray_to_local(sc.g_inv + 12 * (size_t)sc.chain[k], r);
+    const uint32_t* rec = sc.hier_rec + 8 * (size_t)node;  // the node's path in one 32-byte line (pt_api.hip) instead of chain_off -> chain
+    const uint32_t len = rec[0] & 255u;
+    if (len == 255u) {  // more than seven levels
+        for (uint32_t k = sc.chain_off[node]; k < sc.chain_off[node + 1]; k++) r = pt_ray_to_local(sc.g_inv + 12 * (size_t)sc.chain[k], r);
+        return r;
+    }
+    for (uint32_t k = 0; k < len; k++) r = pt_ray_to_local(sc.g_inv + 12 * (size_t)rec[1 + k], r);
     return r;
 }
 
@@ -947,17 +953,51 @@ PT_HD void pt_sload_mat12(const double* p, double m[12]) {
 #pragma unroll
     for (int k = 0; k < 4; k++) m[8 + k] = pt_f64_of(b[2 * k], b[2 * k + 1]);
 }
-// pt_node_local_ray<true> for a wave-uniform node: the path and every SceneNode's inverse come through the scalar cache
-PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray) {
-    const uint32_t k0 = PT_UNIFORM_U32(sc.chain_off[node]), k1 = PT_UNIFORM_U32(sc.chain_off[node + 1]);
+// May a level whose matrices are the identity be skipped for this ray? ((1 x + 0 y) + 0 z) + 0 is x bit for bit unless x is -0 (which
+// the additions turn into +0) or something is not finite (0 times infinity). Wave-uniform: true when no lane's ray has such a component.
+PT_HD bool pt_ray_identity_safe(const PtRay& r, bool has_ray) {
+    auto odd = [](double v) {
+        union { double d; uint32_t u[2]; } c; c.d = v;
+        return c.u[1] == 0x80000000u || (c.u[1] & 0x7FF00000u) == 0x7FF00000u;  // -0 (or a negative denormal: taken along) / infinity / NaN
+    };
+    const bool bad = has_ray && (odd(r.o.x) || odd(r.o.y) || odd(r.o.z) || odd(r.d.x) || odd(r.d.y) || odd(r.d.z));
+#if defined(__HIP_DEVICE_COMPILE__)
+    return !__any(bad);
+#else
+    return !bad;
+#endif
+}
+// pt_node_local_ray<true> for a wave-uniform node: the path (hier_rec: one scalar fetch) and every SceneNode's inverse come through the
+// scalar cache. identity_ok = pt_ray_identity_safe(ray), worked out once per walk: leading levels that are the identity are skipped then.
+PT_HD PtRay pt_node_local_ray_rec(const PtSceneView& sc, uint32_t node, const pt_u32x8& rec, const PtRay& ray, bool identity_ok) {
     PtRay r = ray;
-    for (uint32_t k = k0; k < k1; k++) {
-        const uint32_t g = PT_UNIFORM_U32(sc.chain[k]);
+    const uint32_t len = rec[0] & 255u;
+    if (len == 255u) {  // a path of more than seven levels
+        const uint32_t k0 = PT_UNIFORM_U32(sc.chain_off[node]), k1 = PT_UNIFORM_U32(sc.chain_off[node + 1]);
+        for (uint32_t k = k0; k < k1; k++) {
+            const uint32_t g = PT_UNIFORM_U32(sc.chain[k]);
+            double m[12];
+            pt_sload_mat12(sc.g_inv + 12 * (size_t)g, m);
+            r = pt_ray_to_local(m, r);
+        }
+        return r;
+    }
+    bool untouched = identity_ok;  // the ray is still the world ray
+    uint32_t ids[7] = {rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7]};
+    for (uint32_t k = 0; k < len; k++) {
+        if (untouched && ((rec[0] >> (8u + k)) & 1u)) continue;
+        untouched = false;
+        uint32_t g = ids[0];
+#pragma unroll
+        for (int j = 1; j < 7; j++) g = k == (uint32_t)j ? ids[j] : g;
         double m[12];
         pt_sload_mat12(sc.g_inv + 12 * (size_t)g, m);
         r = pt_ray_to_local(m, r);
     }
     return r;
+}
+PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray, bool identity_ok) {
+    return pt_node_local_ray_rec(sc, node, pt_sload8(sc.hier_rec + 8 * (size_t)node), ray, identity_ok);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1132,7 +1172,7 @@ PT_HD pt_u32x16 pt_sload_node(const void* base, uint32_t index) {
 
 // One flattened node against every participating lane's ray; `node` is wave-uniform.
 template <bool STATS, bool HIER>
-PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray, PtHit& best, PtCounters* cnt) {
+PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray, bool identity_ok, PtHit& best, PtCounters* cnt) {
     // the node's record in one round trip through the scalar cache: {type, data, flags, material} and rows 0..2 of its inverse
     pt_u32x4 info;
     pt_u32x16 a;  // doubles 0..7 of the 3x4 inverse
@@ -1140,21 +1180,26 @@ PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRa
     const void* info_ptr = sc.info + 4 * (size_t)node;
     const void* rec = sc.inv + 12 * (size_t)node;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (HIER) {
-        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(info) : "s"(pt_uniform_ptr(info_ptr)) : "memory");
+    if (HIER) {  // ... and the node's path record (hier_rec) instead of a composed inverse
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(info), "=&s"(b) : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(sc.hier_rec + 8 * (size_t)node)) : "memory");
     } else {
         asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(info), "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(rec)) : "memory");
     }
 #else
     info = *static_cast<const pt_u32x4*>(info_ptr);
-    a = *static_cast<const pt_u32x16*>(rec);
-    b = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(rec) + 64);
+    if (HIER) {
+        b = *reinterpret_cast<const pt_u32x8*>(sc.hier_rec + 8 * (size_t)node);
+    } else {
+        a = *static_cast<const pt_u32x16*>(rec);
+        b = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(rec) + 64);
+    }
 #endif
     const uint32_t type = info[0], data = info[1];
     PtRay local;
     if (HIER) {
-        local = pt_node_local_ray_uniform(sc, node, ray);
+        local = pt_node_local_ray_rec(sc, node, b, ray, identity_ok);
     } else {
         double m[12];
 #pragma unroll
@@ -1257,6 +1302,7 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     unsigned long long in = ~0ull;      // wave-uniform: lanes whose rays reach the current node's box
     int oct;
     const PtRayPk q = pt_raypk(ray, has_ray, &oct);
+    const bool identity_ok = HIER && pt_ray_identity_safe(ray, has_ray);  // (wave-uniform) levels of a path that are the identity may be skipped
     float tm = INFINITY;                 // best.t as the f32 bound of the slab test, rounded up; follows best.t
     uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
     int sp = 0;                          // words on the stack
@@ -1296,7 +1342,7 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
             const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
             if (alive && (!STATS || (in & self))) {
                 if (STATS) cnt->n_leaf++;
-                if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, best, cnt)) {
+                if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, identity_ok, best, cnt)) {
                     tm = pt_tmax32(best.t);
                     if (any) alive = false;
                 }
@@ -1331,6 +1377,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     unsigned long long pmask = PT_BALLOT(alive && part);  // the lanes the slab test's results count for, as a wave-uniform mask
     PtRay local = ray;        // the ray in the space of the tree being walked
     PtRayPk q = pt_raypk(ray);
+    const bool identity_ok = HIER && pt_ray_identity_safe(ray, has_ray);  // (wave-uniform) levels of a path that are the identity may be skipped
     float tm = INFINITY;      // best.t as the f32 bound of the slab test (t means the same in every space, ray.rs:130-135)
     uint32_t inst = PT_NO_HIT;  // wave-uniform: flat node of the mesh instance being walked
     uint32_t cur = PT_UNIFORM_U32(sc.tlas_root);
@@ -1397,7 +1444,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         const PtMeshInfo* mi = sc.meshes + data;
                         PtRay lr;
                         if (HIER) {
-                            lr = pt_node_local_ray_uniform(sc, node, ray);
+                            lr = pt_node_local_ray_uniform(sc, node, ray, identity_ok);
                         } else {
                             double m[12];
                             pt_sload_mat12(sc.inv + 12 * (size_t)node, m);
@@ -1432,7 +1479,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         cur = root;
                         entered = true;
                     } else if (alive) {
-                        if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, best, cnt)) {
+                        if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, identity_ok, best, cnt)) {
                             tm = pt_tmax32(best.t);
                             if (any) alive = false;
                         }

@@ -455,6 +455,33 @@ def test_hierarchical_traversal_matches_oracle(oracle, host, H, name):
     assert_ulp(linear, ref.linear, 0)
 
 
+def test_hierarchical_rays_with_negative_zero_components(oracle, host, H):
+    """Levels of a node's path whose matrices are the identity (the root group of nearly every scene) are skipped by the wave-uniform
+    walk - exact unless a ray component is -0 (the reference's ((1 x + 0 y) + 0 z) + 0 turns it into +0) or not finite, which the walk
+    checks once per ray (pt_ray_identity_safe). Here such rays exist: the light sits at x = -0.0 and the centre column's hit points have
+    x = +0 exactly, so their shadow rays get a direction component (-0) - (+0) = -0; odd width, centre samples. Image, f64 means and ray
+    counts must be the oracle's in the hierarchical semantics (and in flat_scene, which has no such levels)."""
+    mats = [Material(diffuse=(0.7, 0.4, 0.2), specular=(0.3, 0.3, 0.3), shininess=25.0), Material(diffuse=(0.2, 0.5, 0.8), specular=(0.2, 0.2, 0.2), shininess=10.0)]
+    kids = [Node.geo(Plane(), mats[0]).scaled(12.0).translated((0.0, -1.0, 0.0)),
+            Node.geo(Sphere(), mats[1]).translated((0.0, 0.0, 0.0)),
+            Node.group([Node.geo(Cube(), mats[1]).scaled(0.8).translated((0.0, 1.6, 0.0))]),   # an identity group inside: two identity levels
+            Node.group([Node.geo(Cylinder(), mats[0])]).translated((2.0, 0.0, 0.5))]
+    scene = Scene(root=Node.group(kids), lights=[Light(position=(-0.0, 6.0, 0.0), color=(0.9, 0.9, 0.9)), Light(position=(-0.0, 2.0, 7.0), color=(0.4, 0.4, 0.4))],
+                  ambient=(0.2, 0.2, 0.2))
+    cam = Camera(eye=(0.0, 0.5, 9.0), center=(0.0, 0.5, 0.0), fovy_degrees=40.0)
+    w, h = 129, 97
+    bg = default_background(w, h)
+    for tr, om in ((H.TRAVERSE_HIER, oracle.MODE_HIER), (H.TRAVERSE_FLAT, oracle.MODE_FLAT)):
+        r = host.Renderer(host_glue.host_scene(scene), tr)
+        rgb, linear, st = r.render(host_glue.cam10(cam), w, h, bg, stats=True)
+        r.close()
+        ref = oracle.render(oracle.pack(scene), cam, w, h, mode=om)
+        for k in ("primary", "shadow", "hits"):
+            assert st[k] == ref.stats[k], k
+        assert np.array_equal(rgb, ref.rgb)
+        assert_ulp(linear, ref.linear, 0)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_hierarchical_traversal_random_scenes(oracle, host, H, seed):
     """random_scene: shared subtrees under two parents (instancing), nested transformed groups, mirrors, glass, meshes,
