@@ -618,13 +618,7 @@ PT_HD PtVec3 pt_light_term(PtVec3 lcol, PtVec3 falloff, PtVec3 light_dir, double
         double nhs = pt_pow(fmax(pt_dot(N, half), 0.0), 4.0 * shininess);
         specular = (ks * lcol) * nhs;
     }
-    const PtVec3 sum = diffuse + specular;
-    // A light without falloff (light.rs:21-29: the default, c0 = 1, c1 = c2 = 0) has an attenuation of exactly 1.0, and x / 1.0 is x for
-    // every x: where that holds for every lane here, three f64 divisions (33 vector instructions) need not be issued.
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (!__any(attenuation != 1.0)) return sum;
-#endif
-    return sum / attenuation;
+    return (diffuse + specular) / attenuation;
 }
 
 // Runs the lane's interpreter until it needs a ray traced (L.has_ray) or its sample is finished
