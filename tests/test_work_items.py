@@ -67,6 +67,22 @@ def test_ranks_share_the_slice_without_gap_or_overlap(H, ranks, samples):
     assert np.array_equal(total, np.where(full, samples, 0))
 
 
+@pytest.mark.parametrize("w,h,rect,samples,ranks", [(8191, 9, (0, 0, 8190, 8), 100, 1),     # 1024 tiles a row (a power of two), 13 chunk groups
+                                                  (8185, 17, (3, 0, 8183, 16), 999, 3),   # 1023 tiles a row, 125 chunk groups, three ranks
+                                                  (24007, 8, (0, 0, 24006, 7), 24, 7),    # 3001 tiles a row (a prime), seven ranks
+                                                  (1, 4099, (0, 0, 0, 4098), 9, 1)])      # one tile a row, 513 rows of tiles
+def test_divisions_without_a_divider(H, w, h, rect, samples, ranks):
+    """pt_item_lane_fast (what the kernels run: shifts, masks and two multiply-high divisions with constants from the host, PtFastDiv) against
+    pt_item_lane (plain / and %): pt_test_work_items fails if a single lane of a single item differs. Divisors that are powers of two, primes,
+    one; thousands of tiles a row; hundreds of chunk groups."""
+    total = np.zeros((h, w), dtype=np.uint32)
+    for rank in range(ranks):
+        count, _, chunk_sum, _, _ = replay(H, w, h, rect, samples, rank, ranks)
+        assert np.array_equal(count, chunk_sum)
+        total += count
+    assert np.array_equal(total, np.where(own_tiles(w, h, rect, 0, 1), samples, 0))
+
+
 @pytest.mark.parametrize("chunks", ["1", "2", "4", "8"])
 def test_forced_chunk_layouts(H, monkeypatch, chunks):
     """PORTRAYER_LANE_CHUNKS: every layout of a wavefront the switch allows covers the same samples."""
