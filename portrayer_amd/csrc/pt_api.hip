@@ -986,7 +986,14 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     if (c->spawns) a.run_variant = (chain && a.park_slots) ? PT_RUN_CHAIN : (a.park_slots ? (fork ? PT_RUN_INTERP_FORK : PT_RUN_INTERP_PARK) : PT_RUN_INTERP);
     else if (pt_interpreter_forced()) a.run_variant = a.four_waves ? PT_RUN_INTERP4 : PT_RUN_INTERP;
     else a.run_variant = a.four_waves == 5 ? PT_RUN_LINE5 : (a.four_waves ? PT_RUN_LINE4 : PT_RUN_LINE3);
-    if (a.run_variant == PT_RUN_CHAIN) a.park_slots = 0;  // no frame in LDS: the parked colours go straight to the lane's HBM lines
+    if (a.run_variant == PT_RUN_CHAIN) {
+        a.park_slots = 0;  // no frame in LDS: the parked colours go straight to the lane's HBM lines
+        // 4 waves per SIMD in the flat_scene semantics (mirror scene 25.5 -> 26.8 Gray/s, c34: ten bounces per sample leave a lot of latency to hide),
+        // 3 in the hierarchical ones (182 spilled registers at 128: 19.3 -> 14.8) and the k-d ones. PORTRAYER_CHAIN_WAVES=3|4 overrides.
+        const bool flat_sem = a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_FLAT_KDMESH;
+        a.four_waves = flat_sem ? 4 : 0;
+        if (const char* e = getenv("PORTRAYER_CHAIN_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode != PT_MODE_KD) ? 4 : 0;
+    }
     size_t block_budget = a.four_waves == 5 ? 31 * 1024 : (a.four_waves ? 39 * 1024 : 52 * 1024);  // 3 x 52 KB, 4 x 39 KB or 5 x 31 KB of the CU's 160 KB
     if (const char* e = getenv("PORTRAYER_LDS_BUDGET_KB")) block_budget = (size_t)std::max(16, std::min(160, atoi(e))) * 1024;  // experiment: 80 = two blocks per CU
     const size_t frame_bytes = (size_t)(PT_LDS_FRAME_F64 + a.park_slots * PT_PARK_F64) * PT_BLOCK * 8;

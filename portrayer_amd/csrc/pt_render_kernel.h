@@ -339,7 +339,10 @@ static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_
         if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 2>, lds, a, n_cu, stream, grid_out, launch);
         return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
 #endif
-    case PT_RUN_CHAIN: return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 3, true>, lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_CHAIN:
+        if constexpr (MODE != PT_MODE_KD)
+            if (a.four_waves == 4) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 4, true>, lds, a, n_cu, stream, grid_out, launch);
+        return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 3, true>, lds, a, n_cu, stream, grid_out, launch);
     case PT_RUN_LINE5:  // mesh-free scenes in the flat_scene / hierarchical semantics: 96 registers, 5 waves per SIMD
         if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>, lds, a, n_cu, stream, grid_out, launch);
         [[fallthrough]];
