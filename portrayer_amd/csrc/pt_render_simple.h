@@ -227,6 +227,9 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                 PtVec3 kd = pt_v3(m[0], m[1], m[2]);
                 if (TEX && (ftag & PT_FS_TEXEL)) kd = pt_v3(sc.srgb_lut[ftag & 255u], sc.srgb_lut[(ftag >> 8) & 255u], sc.srgb_lut[(ftag >> 16) & 255u]);
                 color = pt_v3(sc.ambient[0], sc.ambient[1], sc.ambient[2]) * kd;  // material.rs:148
+#ifndef PT_NO_LDS_COLOR  // the colour so far and the distance to the light wait in the lane's LDS column (slots of P and the tag, unused here) while the shadow ray is walked: eight registers the walks need more
+                fr.set_l3(PT_L_P, color);
+#endif
             }
             PT_SEC_END(4);
             for (uint32_t li = 0; li < sc.n_lights; li++) {  // material.rs:149-210, one light after the other
@@ -254,6 +257,9 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                     PtVec3 hit_to_light = lpos - sray.o;
                     light_dist = pt_length(hit_to_light);
                     sray.d = hit_to_light / light_dist;
+#ifndef PT_NO_LDS_COLOR
+                    fr.l(PT_L_TAG) = light_dist;
+#endif
                     if (STATS) cnt.shadow++;
                 }
                 if (area) udraw += 2;
@@ -269,11 +275,18 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                     const double* m = sc.materials + 10 * (size_t)mat;
                     PtVec3 kd = pt_v3(m[0], m[1], m[2]), ks = pt_v3(m[3], m[4], m[5]);
                     if (TEX && (ftag & PT_FS_TEXEL)) kd = pt_v3(sc.srgb_lut[ftag & 255u], sc.srgb_lut[(ftag >> 8) & 255u], sc.srgb_lut[(ftag >> 16) & 255u]);
+#ifndef PT_NO_LDS_COLOR
+                    fr.set_l3(PT_L_P, fr.l3(PT_L_P) + pt_light_term(pt_v3(lc[0], lc[1], lf[0]), pt_v3(lf[1], lf[2], lf[3]), sray.d, fr.l(PT_L_TAG), fr.l3(PT_L_N), fr.l3(PT_L_D), kd, ks, m[6]));
+#else
                     color = color + pt_light_term(pt_v3(lc[0], lc[1], lf[0]), pt_v3(lf[1], lf[2], lf[3]), sray.d, light_dist, fr.l3(PT_L_N), fr.l3(PT_L_D), kd, ks, m[6]);
+#endif
                 }
                 PT_SEC_END(7);
             }
             if (shaded) {
+#ifndef PT_NO_LDS_COLOR
+                color = fr.l3(PT_L_P);
+#endif
                 const double* m = sc.materials + 10 * (size_t)mat;
                 const double reflectivity = m[7], glossy = m[8];
                 if (!CHAIN || !(reflectivity > 0.0)) {  // material.rs:216: nothing is reflected
