@@ -990,7 +990,9 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
         a.park_slots = 0;  // no frame in LDS: the parked colours go straight to the lane's HBM lines
         // 4 waves per SIMD in the flat_scene semantics (mirror scene 25.5 -> 26.8 Gray/s, c34: ten bounces per sample leave a lot of latency to hide),
         // 3 in the hierarchical ones (182 spilled registers at 128: 19.3 -> 14.8) and the k-d ones. PORTRAYER_CHAIN_WAVES=3|4 overrides.
-        const bool flat_sem = a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_FLAT_KDMESH;
+        // (Only where that was measured or the compiler's figures are like the measured case's: untextured, no KDMesh trees - those
+        // instantiations spill 57 / 142 registers at 128.)
+        const bool flat_sem = (a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_FLAT_NOMESH) && !tex;
         a.four_waves = flat_sem ? 4 : 0;
         if (const char* e = getenv("PORTRAYER_CHAIN_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode != PT_MODE_KD) ? 4 : 0;
     }

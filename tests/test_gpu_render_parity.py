@@ -428,12 +428,18 @@ def test_chain_kernel_matches_interpreter_and_oracle(oracle, host, H, monkeypatc
     rgb, linear, st = r.render(host_glue.cam10(cam), w, h, bg, stats=True, **kw)
     fast, fast_linear, st1 = r.render(host_glue.cam10(cam), w, h, bg, **kw)  # the non-counting instantiation
     assert st["kernel_variant"] & H.KERNEL_CHAIN and st1["kernel_variant"] & H.KERNEL_CHAIN
-    if mode == "flat":  # 4 waves per SIMD by default in these semantics; the 3-wave instantiation must render the same
+    if mode == "flat" and st1["kernel_mode"] in (1, 3):  # flat_scene semantics without KDMesh trees: 4 waves per SIMD by default; the 3-wave instantiation must render the same
         assert st1["kernel_variant"] & H.KERNEL_WAVES_MASK == 4
         monkeypatch.setenv("PORTRAYER_CHAIN_WAVES", "3")
         three, three_linear, st3 = r.render(host_glue.cam10(cam), w, h, bg, **kw)
         assert st3["kernel_variant"] & H.KERNEL_WAVES_MASK == 3 and st3["kernel_variant"] & H.KERNEL_CHAIN
         assert np.array_equal(three, fast) and np.array_equal(three_linear, fast_linear)
+    elif mode == "flat":  # with KDMesh trees: 3 waves by default; the 4-wave instantiation must render the same
+        assert st1["kernel_variant"] & H.KERNEL_WAVES_MASK == 3
+        monkeypatch.setenv("PORTRAYER_CHAIN_WAVES", "4")
+        four, four_linear, st4 = r.render(host_glue.cam10(cam), w, h, bg, **kw)
+        assert st4["kernel_variant"] & H.KERNEL_WAVES_MASK == 4 and st4["kernel_variant"] & H.KERNEL_CHAIN
+        assert np.array_equal(four, fast) and np.array_equal(four_linear, fast_linear)
     monkeypatch.setenv("PORTRAYER_CHAIN", "0")
     old, old_linear, st0 = r.render(host_glue.cam10(cam), w, h, bg, stats=True, **kw)
     r.close()
