@@ -184,6 +184,7 @@ struct pt_context {
     bool one_ray = false;      // ... and every reflective material is opaque (no index of refraction): a hit spawns at most one ray, the recursion is a chain
     bool forkable = false;     // ... and no hit draws random numbers after the jitter (no area light, no glossy material): refracted subtrees may be walked by other lanes
     uint32_t launch_seq = 0;   // PtRenderArgs::launch_nonce
+    bool four_waves_untextured = false;  // ... or, while the scene has no texture maps: any scene with plain Mesh instances
     bool four_waves = false;   // traversal-heavy scene without reflective materials, flat_scene / hierarchical semantics: a kernel compiled for more than 3 waves per SIMD
     bool five_waves = false;   // ... mesh-free: 5 waves per SIMD (96 registers)
     PtSceneView view;
@@ -696,8 +697,13 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         // hierarchical semantics (round 3, straight-line kernel): mesh-free scenes with many nodes gain like flat_scene ones (big-scene 25.7 ->
         // 29.4 Gray/s at 4 waves); with mesh instances the walk carries a second ray and spills at 128 registers (macho-cows 16.4 -> 12.0) unless
         // the triangle trees dominate (the 1.25 M-triangle soup: equal)
+        // Since the register work of round 3 (arguments re-read, colour parked in LDS, an instantiation of the hierarchical semantics without
+        // the KDMesh walker) scenes with plain Mesh instances of any size gain too (c41: macho-cows 21.4 -> 23.4 Gray/s, hierarchical 18.7 -> 19.7);
+        // with KDMesh trees the kernels still spill 100+ registers at 128 and stay at 3 waves unless the triangle trees dominate.
+        const bool plain_meshes = s->n_meshes > 0 && !any_kdmesh;
         c->four_waves = !c->spawns && ((traverse == PT_TRAVERSE_FLAT && (n >= 256 || instanced_tris >= 65536)) ||
                                        (traverse == PT_TRAVERSE_HIER && ((s->n_meshes == 0 && n >= 256) || instanced_tris >= 65536)));
+        c->four_waves_untextured = !c->spawns && plain_meshes && (traverse == PT_TRAVERSE_FLAT || traverse == PT_TRAVERSE_HIER);  // (measured untextured only)
         // mesh-free scenes go one further: 5 waves per SIMD (96 registers, 17 of the kernel's spilled; big-scene 34.4 -> 37.0, hierarchical
         // 29.4 -> 32.5 Gray/s; the k-d walk, 50 spilled, loses and stays at 4)
         c->five_waves = c->four_waves && s->n_meshes == 0 && traverse != PT_TRAVERSE_KD;
@@ -799,7 +805,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.mkd_item_box = v.mkd_box ? (const float*)c->mkd_item_box.p : nullptr;
     v.mode = traverse == PT_TRAVERSE_KD ? (s->n_meshes == 0 ? PT_MODE_KD_NOMESH : PT_MODE_KD) : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
     if (traverse == PT_TRAVERSE_HIER) {  // the general walker (meshes and KDMesh trees compiled in), or its mesh-free instantiation
-        v.mode = s->n_meshes == 0 ? PT_MODE_HIER_NOMESH : PT_MODE_HIER;
+        v.mode = s->n_meshes == 0 ? PT_MODE_HIER_NOMESH : (any_kdmesh ? PT_MODE_HIER : PT_MODE_HIER_MESH);
         v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
         v.chain_off = (const uint32_t*)c->chain_off.p; v.chain = (const uint32_t*)c->chain.p; v.dfs_rank = (const uint32_t*)c->dfs_rank.p;
         v.hier_rec = (const uint32_t*)c->hier_rec.p;
@@ -868,6 +874,7 @@ static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipSt
     case PT_MODE_HIER: return pt_launch_mode_5(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_HIER_MESH: return pt_launch_mode_8(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     default: return pt_launch_mode_1(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     }
 }
@@ -962,7 +969,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // Scenes whose hits spawn rays need the interpreter kernel (3 waves per SIMD); the others run the straight-line kernel at 3 or
     // 4 waves per SIMD. PORTRAYER_INTERP=1 (builds with -DPT_KEEP_INTERP): the interpreter on those too, for A/B runs.
     const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH;
-    a.four_waves = (!c->spawns && c->four_waves) ? (c->five_waves ? 5 : 4) : 0;
+    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex))) ? (c->five_waves ? 5 : 4) : 0;
     if (const char* e = getenv("PORTRAYER_WAVES")) {
         const int wv = atoi(e);
         a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? 5 : 4) : 0;
@@ -992,7 +999,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
         // 3 in the hierarchical ones (182 spilled registers at 128: 19.3 -> 14.8) and the k-d ones. PORTRAYER_CHAIN_WAVES=3|4 overrides.
         // (Only where that was measured or the compiler's figures are like the measured case's: untextured, no KDMesh trees - those
         // instantiations spill 57 / 142 registers at 128.)
-        const bool flat_sem = (a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_FLAT_NOMESH) && !tex;
+        const bool flat_sem = (a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_MESH) && !tex;  // (HIER_MESH: 22.2 -> 24.2, c41)
         a.four_waves = flat_sem ? 4 : 0;
         if (const char* e = getenv("PORTRAYER_CHAIN_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode != PT_MODE_KD) ? 4 : 0;
     }
@@ -1303,6 +1310,7 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     case PT_MODE_HIER: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER>())); break;
     case PT_MODE_HIER_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER_NOMESH>())); break;
     case PT_MODE_KD_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_KD_NOMESH>())); break;
+    case PT_MODE_HIER_MESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER_MESH>())); break;
     default: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT>())); break;
     }
     PT_HIP(c, hipGetLastError());

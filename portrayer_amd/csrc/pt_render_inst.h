@@ -1,5 +1,5 @@
 // Launchers of the render kernel, one per traversal mode: each is defined in its own object
-// (pt_render_inst.hip compiled with -DPT_INST_MODE=<mode>) so that the six sets of kernel
+// (pt_render_inst.hip compiled with -DPT_INST_MODE=<mode>) so that the eight sets of kernel
 // instantiations compile side by side.
 #pragma once
 
@@ -16,3 +16,4 @@ PT_DECLARE_MODE_LAUNCHER(4);  // PT_MODE_FLAT_KDMESH
 PT_DECLARE_MODE_LAUNCHER(5);  // PT_MODE_HIER
 PT_DECLARE_MODE_LAUNCHER(6);  // PT_MODE_HIER_NOMESH
 PT_DECLARE_MODE_LAUNCHER(7);  // PT_MODE_KD_NOMESH
+PT_DECLARE_MODE_LAUNCHER(8);  // PT_MODE_HIER_MESH

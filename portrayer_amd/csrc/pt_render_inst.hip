@@ -1,5 +1,5 @@
 // One traversal mode's instantiations of pt_render_kernel (counting / plain, textured / untextured,
-// the variants listed in pt_render_kernel.h) and their launcher. Compiled once per mode: -DPT_INST_MODE=1..7 (Makefile).
+// the variants listed in pt_render_kernel.h) and their launcher. Compiled once per mode: -DPT_INST_MODE=1..8 (Makefile).
 // The texture routine (pt_apply_maps) is out of line so that untextured hits keep their register budget - except in the flat_scene
 // kernels of scenes with KDMesh trees, where inlining it measured +10 % (transmission-refraction 11.5 -> 12.6 Gray/s; the same scene
 // in the hierarchical semantics loses 7 % inlined: profiles/r03/notes.md section 4).

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 #ifndef PT_NO_ARGS_AGAIN
             const PtRenderArgs& a = pt_args_again(a0);  // what the interpreter and this pass's walk need of the arguments is fetched now, not kept from the top of the kernel on (pt_render_simple.h)
 #endif
-            if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH, PARK, FORK>(a, L, hit, fr, &cnt);
+            if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH || MODE == PT_MODE_HIER_MESH, PARK, FORK>(a, L, hit, fr, &cnt);
             if (FORK) {
                 // Offers and takers, matched by rank: the k-th lane that parked a frame with a refracted ray in this pass writes its
                 // thread index to slot k of the wavefront's queue in LDS (the first words of its traversal stack, free between

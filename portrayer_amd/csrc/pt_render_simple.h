@@ -72,9 +72,9 @@ PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, 
     if (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) {
         const int words = a.stack_lds_cap * 64;
         pt_trace_packet<STATS, MODE == PT_MODE_HIER_NOMESH>(a.scene, ray, tracing, any, hit, lds + (size_t)wave * words, words, a.overflow_flag, cnt);
-    } else if (MODE == PT_MODE_FLAT) {
+    } else if (MODE == PT_MODE_FLAT || MODE == PT_MODE_HIER_MESH) {
         const int words = a.stack_lds_cap * 64;
-        pt_trace_packet_mesh<STATS, false, false>(a.scene, ray, tracing, any, hit, lds + (size_t)wave * words, words, stk, a.overflow_flag, cnt);
+        pt_trace_packet_mesh<STATS, false, MODE == PT_MODE_HIER_MESH>(a.scene, ray, tracing, any, hit, lds + (size_t)wave * words, words, stk, a.overflow_flag, cnt);
     } else if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
         const int rows = a.stack_lds_cap >= 16 ? 8 : (a.stack_lds_cap >= 8 ? 3 : (a.stack_lds_cap >= 4 ? 2 : 1));  // of the wavefront's stack (64 entries each); the lanes' own stacks get the rest
         PtStackSpill lane_stk = stk;
@@ -113,7 +113,7 @@ PT_HD uint32_t* pt_fork_queue(const PtRenderArgs& a, uint32_t* lds) {
 // Lanes whose chains have ended idle until the wavefront's longest chain has; no interpreter, no stage word, no frame in LDS.
 template <int MODE, bool STATS, bool TEX, int WAVES, bool CHAIN = false>
 __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRenderArgs a0) {
-    constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH;
+    constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH || MODE == PT_MODE_HIER_MESH;
     extern __shared__ uint32_t pt_lds[];
     const PtRenderArgs& a = a0;
     const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;

@@ -1512,5 +1512,6 @@ PT_HD void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hi
     else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_HIER) pt_trace_flat<STATS, true, true, true>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_HIER_NOMESH) pt_trace_flat<STATS, false, false, true>(sc, ray, any, hit, stk, cnt);
+    else if (MODE == PT_MODE_HIER_MESH) pt_trace_flat<STATS, true, false, true>(sc, ray, any, hit, stk, cnt);
     else pt_trace_flat<STATS, true, false>(sc, ray, any, hit, stk, cnt);
 }

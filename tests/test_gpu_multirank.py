@@ -237,5 +237,5 @@ def test_bench_single_gpu_line_carries_the_contract_fields():
         assert k in d, k
     r = d["roofline"]
     assert r["bound"] == "valu" and r["unit"].startswith("T lane-ops/s") and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
-    assert "pt_render_simple_kernel<1, false, false, 3, false>" in r["kernel"], "macho-cows: meshes, nothing reflective, 3 waves"
+    assert "pt_render_simple_kernel<1, false, false, 4, false>" in r["kernel"], "macho-cows: plain meshes, nothing reflective, untextured: 4 waves"
     assert r["hbm"]["needed_bytes"] > 0 and d["config"]["collective"] is None
