@@ -1,4 +1,4 @@
-# round 3, call 39: the round's final profile set on the default build (kernel trace + PMC passes per workload), the default bench line, the workload table, the suite
+# (round 3, call c39) The round's final profile set on the default build (kernel trace + PMC passes per workload), the default bench line, the workload table, the suite
 timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/c39_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/c39_pytest.log
 bash profiles/run_profile.sh r03_bigscene --workload big-scene > gpurun_out/c39_prof1.log 2>&1
 bash profiles/run_profile.sh r03_hier --workload big-scene --traversal hier > gpurun_out/c39_prof2.log 2>&1
