@@ -1036,8 +1036,9 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     int rc;
     const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_STRIDE * sizeof(double) : 16;
     if ((rc = pt_reserve(c, c->spill, spill_bytes))) return rc;
-    // + 8: the wavefront's own stack may take up to eight of the LDS rows from the lanes' stacks (pt_render_kernel)
-    if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * (size_t)std::max(a.scene.stack_cap - a.stack_lds_cap + 8, 0) * 4))) return rc;
+    // + wave_rows: the wavefront's own stack takes LDS rows from the lanes' stacks (pt_wave_rows, pt_render_simple.h): eight, or what a deep tree needs
+    const int wave_rows = std::min(std::max(8, (a.scene.stack_cap + 63) / 64), std::max(a.stack_lds_cap, 8));  // (pt_wave_rows: at most this many)
+    if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * (size_t)std::max(a.scene.stack_cap - a.stack_lds_cap + wave_rows, 0) * 4))) return rc;
     if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4))) return rc;
     if ((rc = pt_reserve(c, c->accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
     a.accum = (double*)c->accum.p;

@@ -51,6 +51,18 @@ PT_HD const PtRenderArgs& pt_args_again(const PtRenderArgs& a) {
 #endif
 }
 
+// Kernels whose lanes need traversal stacks of their own (KDMesh trees) split the block's LDS stack area: `rows` x 64 entries for each
+// wavefront's own stack, the rest for the lanes' (which continue in HBM, PtStackSpill). The wavefront's stack has no HBM part: it gets as
+// many rows as the deepest walk of THIS scene can have pending (scene.stack_cap bounds that), at the lanes' expense if need be - so a deep
+// device-built tree costs lane rows, not the render (PT_ERR_TRAVERSAL is left for scenes beyond stack_lds_cap x 64 entries).
+PT_HD int pt_wave_rows(const PtRenderArgs& a) {
+    const int cap = a.stack_lds_cap;
+    int rows = cap >= 16 ? 8 : (cap >= 8 ? 3 : (cap >= 4 ? 2 : 1));
+    const int need = (a.scene.stack_cap + 63) / 64;
+    if (need > rows) rows = need < cap ? need : cap;
+    return rows;
+}
+
 // One ray kind for the whole wavefront: `tracing` lanes carry `ray`; result in `hit` (untouched for the other lanes).
 template <int MODE, bool STATS>
 PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, bool any, PtHit& hit, const PtStackSpill& stk, uint32_t* lds, PtCounters* cnt) {
@@ -76,7 +88,7 @@ PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, 
         const int words = a.stack_lds_cap * 64;
         pt_trace_packet_mesh<STATS, false, MODE == PT_MODE_HIER_MESH>(a.scene, ray, tracing, any, hit, lds + (size_t)wave * words, words, stk, a.overflow_flag, cnt);
     } else if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
-        const int rows = a.stack_lds_cap >= 16 ? 8 : (a.stack_lds_cap >= 8 ? 3 : (a.stack_lds_cap >= 4 ? 2 : 1));  // of the wavefront's stack (64 entries each); the lanes' own stacks get the rest
+        const int rows = pt_wave_rows(a);  // of the wavefront's stack (64 entries each); the lanes' own stacks get the rest
         PtStackSpill lane_stk = stk;
         lane_stk.cap = a.stack_lds_cap - rows;
         pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, ray, tracing, any, hit, lds + (size_t)lane_stk.cap * PT_BLOCK + (size_t)wave * rows * 64, rows * 64, lane_stk,
@@ -96,7 +108,7 @@ PT_HD uint32_t* pt_fork_queue(const PtRenderArgs& a, uint32_t* lds) {
     const uint32_t wave = 0;
 #endif
     if (MODE == PT_MODE_FLAT_KDMESH || MODE == PT_MODE_HIER) {
-        const int rows = a.stack_lds_cap >= 16 ? 8 : (a.stack_lds_cap >= 8 ? 3 : (a.stack_lds_cap >= 4 ? 2 : 1));
+        const int rows = pt_wave_rows(a);
         return lds + (size_t)(a.stack_lds_cap - rows) * PT_BLOCK + (size_t)wave * rows * 64;
     }
     if (MODE == PT_MODE_KD || MODE == PT_MODE_KD_NOMESH) return lds + (size_t)(a.stack_lds_cap - 1) * PT_BLOCK + (size_t)wave * 64;  // the lanes' last row (per-lane walks: free between them too)

@@ -573,6 +573,30 @@ def test_traversal_stack_beyond_lds_gives_the_same_image(host, H, monkeypatch, n
         assert out[None][2][k] == out["1"][2][k], k
 
 
+@pytest.mark.parametrize("mode", ["flat", "hier"])
+def test_deep_trees_take_lds_rows_from_the_lanes_not_the_render(oracle, host, H, monkeypatch, mode):
+    """Kernels whose lanes keep stacks of their own (KDMesh trees) give the wavefront's own stack `rows` x 64 entries of LDS; a scene whose
+    trees could have more pending than that (scene.stack_cap) gets more rows, taken from the lanes' stacks, which continue in HBM
+    (pt_wave_rows). PORTRAYER_STACK_CAP=450 declares such a depth for a small scene: every row goes to the wavefronts, every lane-stack
+    entry to HBM, and the picture must not change."""
+    scene, cam = random_scene(3)  # Mesh and KDMesh instances, mirrors, glass: the interpreter kernel with a parked frame in LDS (7 rows of stack)
+    tr = H.TRAVERSE_FLAT if mode == "flat" else H.TRAVERSE_HIER
+    w, h = 128, 96
+    out = []
+    for cap in (None, "450"):
+        if cap:
+            monkeypatch.setenv("PORTRAYER_STACK_CAP", cap)
+        r = host.Renderer(host_glue.host_scene(scene), tr)
+        rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=2, seed=5, sample_mode=H.SAMPLE_RNG, stats=True)
+        plain, _, _ = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=2, seed=5, sample_mode=H.SAMPLE_RNG)
+        r.close()
+        assert st["stack_overflow"] == 0 and np.array_equal(plain, rgb)
+        out.append((rgb, linear, st))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    for k in ("primary", "shadow", "reflect", "refract", "hits"):
+        assert out[0][2][k] == out[1][2][k], k
+
+
 @pytest.mark.parametrize("env", [{"PORTRAYER_COLLAPSE": "plain"}, {"PORTRAYER_COLLAPSE": "area"}, {"PORTRAYER_FINE_QUEUES": "0"}, {"PORTRAYER_FINE_QUEUES": "1"},
                                  {"PORTRAYER_FINE_QUEUES": "64"}, {"PORTRAYER_FINE_QUEUES": "0", "PORTRAYER_BATCH_MAX": "1"},
                                  {"PORTRAYER_FINE_QUEUES": "0", "PORTRAYER_ITEM_STRIDE": "golden"}, {"PORTRAYER_LANE_CHUNKS": "1"},
