@@ -185,6 +185,7 @@ struct pt_context {
     bool forkable = false;     // ... and no hit draws random numbers after the jitter (no area light, no glossy material): refracted subtrees may be walked by other lanes
     uint32_t launch_seq = 0;   // PtRenderArgs::launch_nonce
     bool four_waves_untextured = false;  // ... or, while the scene has no texture maps: any scene with plain Mesh instances
+    bool four_waves_hier = false;        // ... or any scene without KDMesh trees in the hierarchical semantics
     bool four_waves = false;   // traversal-heavy scene without reflective materials, flat_scene / hierarchical semantics: a kernel compiled for more than 3 waves per SIMD
     bool five_waves = false;   // ... mesh-free: 5 waves per SIMD (96 registers)
     PtSceneView view;
@@ -703,7 +704,10 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         const bool plain_meshes = s->n_meshes > 0 && !any_kdmesh;
         c->four_waves = !c->spawns && ((traverse == PT_TRAVERSE_FLAT && (n >= 256 || instanced_tris >= 65536)) ||
                                        (traverse == PT_TRAVERSE_HIER && ((s->n_meshes == 0 && n >= 256) || instanced_tris >= 65536)));
-        c->four_waves_untextured = !c->spawns && plain_meshes && (traverse == PT_TRAVERSE_FLAT || traverse == PT_TRAVERSE_HIER);  // (measured untextured only)
+        c->four_waves_untextured = !c->spawns && plain_meshes && (traverse == PT_TRAVERSE_FLAT || traverse == PT_TRAVERSE_HIER);  // (textured: flat_scene loses 10 % at 4 waves, c45)
+        // The hierarchical semantics without KDMesh trees gain at 4 waves whatever the scene (their leaf tests wait for a path record and a matrix per
+        // level): macho-cows +5 %, fish (textured) +5 %, normal-mapping (11 textured primitives) +12 %, the mirror scene's chain kernel +9 % (c41, c45).
+        c->four_waves_hier = !c->spawns && traverse == PT_TRAVERSE_HIER && !any_kdmesh;
         // mesh-free scenes go one further: 5 waves per SIMD (96 registers, 17 of the kernel's spilled; big-scene 34.4 -> 37.0, hierarchical
         // 29.4 -> 32.5 Gray/s; the k-d walk, 50 spilled, loses and stays at 4)
         c->five_waves = c->four_waves && s->n_meshes == 0 && traverse != PT_TRAVERSE_KD;
@@ -969,7 +973,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // Scenes whose hits spawn rays need the interpreter kernel (3 waves per SIMD); the others run the straight-line kernel at 3 or
     // 4 waves per SIMD. PORTRAYER_INTERP=1 (builds with -DPT_KEEP_INTERP): the interpreter on those too, for A/B runs.
     const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH;
-    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex))) ? (c->five_waves ? 5 : 4) : 0;
+    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex) || c->four_waves_hier)) ? (c->five_waves ? 5 : 4) : 0;
     if (const char* e = getenv("PORTRAYER_WAVES")) {
         const int wv = atoi(e);
         a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? 5 : 4) : 0;
