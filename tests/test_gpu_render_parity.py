@@ -51,6 +51,30 @@ CASES = [("single-triangle", (256, 256), "flat"), ("single-triangle", (256, 256)
          ("big-scene", (240, 135), "flat"), ("big-scene", (960, 540), "kd")]
 
 
+@pytest.mark.parametrize("mode", ["flat", "hier"])
+def test_big_scene_five_wave_kernels_every_pixel(oracle, host, H, mode):
+    """The instantiations bench.py's headline and its default-semantics line run - the mesh-free straight-line kernel at 5 waves per SIMD, a
+    wavefront = one pixel's 64 samples - on a frame small enough for the oracle to render every pixel of: the plain (timed) instantiation and
+    the counting one, image, f64 means and ray counts."""
+    sc = host.Scene.example("big-scene", assets=ASSETS)
+    w, h, samples = 160, 90, 64
+    tr, om = (H.TRAVERSE_HIER, oracle.MODE_HIER) if mode == "hier" else (H.TRAVERSE_FLAT, oracle.MODE_FLAT)
+    r = host.Renderer(sc, tr)
+    bg = default_background(w, h)
+    kw = dict(samples=samples, seed=2, sample_mode=H.SAMPLE_RNG)
+    plain, plain_linear, st0 = r.render(sc.camera, w, h, bg, **kw)
+    rgb, linear, st = r.render(sc.camera, w, h, bg, stats=True, **kw)
+    r.close()
+    assert st0["kernel_variant"] == 5 and st0["kernel_mode"] == (6 if mode == "hier" else 3)
+    cam = EXAMPLES["big-scene"]()[1]
+    ref = oracle.render(oracle_from(oracle, sc), cam, w, h, samples=samples, seed=2, jitter=oracle.JITTER_RNG, mode=om)
+    for k in ("primary", "shadow", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert np.array_equal(plain, ref.rgb) and np.array_equal(rgb, ref.rgb)
+    assert_ulp(plain_linear, ref.linear, 0)
+    assert_ulp(linear, ref.linear, 0)
+
+
 @pytest.mark.parametrize("name,size,mode", CASES)
 def test_example_matches_oracle(oracle, host, H, name, size, mode):
     sc = host.Scene.example(name, assets=ASSETS)
