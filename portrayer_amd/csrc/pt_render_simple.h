@@ -186,8 +186,9 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
 #define PT_SEC_SKIP() do { } while (0)
 #define PT_SEC_END(k) do { } while (0)
 #endif
-#ifndef PT_NO_ARGS_AGAIN  // (shadows the kernel's own view of its arguments for the rest of the item; the k-d semantics measured 1.5 % better off without)
-        const PtRenderArgs& a = (MODE == PT_MODE_KD || MODE == PT_MODE_KD_NOMESH) ? a0 : pt_args_again(a0);
+#ifndef PT_NO_ARGS_AGAIN  // (shadows the kernel's own view of its arguments for the rest of the item. The k-d semantics of mesh-free scenes are as fast without
+        // - 30.5 against 30.7 ms on big-scene, c22 / c50 -; with mesh instances they gain like the others: mirror 8.7 -> 9.6 Gray/s, macho-cows 6.7 -> 7.2, c50)
+        const PtRenderArgs& a = MODE == PT_MODE_KD_NOMESH ? a0 : pt_args_again(a0);
         const PtSceneView& sc = a.scene;
 #endif
         // ---- the primary ray of this lane's sample (render.rs:36-41, camera.rs:48-84)
