@@ -518,6 +518,50 @@ def test_hierarchical_rays_with_negative_zero_components(oracle, host, H):
         assert_ulp(linear, ref.linear, 0)
 
 
+@pytest.mark.parametrize("with_mesh", [False, True])
+def test_hierarchical_paths_longer_than_the_record(oracle, host, H, with_mesh):
+    """A flattened node's path record (hier_rec) holds seven levels; deeper paths fall back to the chain arrays - in the wave-uniform
+    leaf test, in the per-lane walk of mesh instances and on the way back up in pt_hit_surface. Ten nested groups, some with the
+    identity, most with small transforms, primitives at depths 3, 8 and 11 (and a mesh at 10): image, f64 means and ray counts == oracle."""
+    from example_scenes import load_mesh
+    mats = [Material(diffuse=(0.8, 0.3, 0.2), specular=(0.3, 0.3, 0.3), shininess=25.0), Material(diffuse=(0.2, 0.6, 0.8), specular=(0.2, 0.2, 0.2), shininess=10.0),
+            Material(diffuse=(0.3, 0.8, 0.3), specular=(0.4, 0.4, 0.4), shininess=50.0)]
+    inner = [Node.geo(Sphere(), mats[0]).scaled(0.7).translated((0.0, 0.4, 0.0))]            # depth 11 under the root
+    if with_mesh:
+        inner.append(Node.geo(Mesh(load_mesh("buckyball.obj"), False), mats[2]).scaled(0.5).translated((1.4, 0.2, 0.3)))
+    node = Node.group(inner)
+    for level in range(9):  # wrap it in nine more groups
+        kids = [node]
+        if level == 2:
+            kids.append(Node.geo(Cube(), mats[1]).scaled(0.6).translated((-1.5, 0.0, 0.5)))   # depth 8
+        if level == 7:
+            kids.append(Node.geo(Cylinder(), mats[2]).scaled((0.5, 1.2, 0.5)).translated((1.6, 0.0, -0.8)))  # depth 3
+        node = Node.group(kids)
+        if level % 3 == 0:
+            node.rotated_y(0.13 * (level + 1))
+        elif level % 3 == 1:
+            node.translated((0.05 * level, 0.02, -0.03 * level)).scaled(1.02)
+        # level % 3 == 2: the identity
+    floor = Node.geo(Plane(), mats[1]).scaled(14.0).translated((0.0, -1.0, 0.0))
+    scene = Scene(root=Node.group([node, floor]), lights=[Light(position=(4.0, 7.0, 6.0), color=(0.9, 0.9, 0.9)), Light(position=(-5.0, 3.0, 4.0), color=(0.4, 0.4, 0.5))],
+                  ambient=(0.2, 0.2, 0.2))
+    cam = Camera(eye=(0.5, 2.0, 8.0), center=(0.0, 0.2, 0.0), fovy_degrees=40.0)
+    w, h = 160, 112
+    bg = default_background(w, h)
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_HIER)
+    kw = dict(samples=4, seed=9, sample_mode=H.SAMPLE_RNG)
+    plain, plain_linear, _ = r.render(host_glue.cam10(cam), w, h, bg, **kw)
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, bg, stats=True, **kw)
+    r.close()
+    ref = oracle.render(oracle.pack(scene), cam, w, h, samples=4, seed=9, jitter=oracle.JITTER_RNG, mode=oracle.MODE_HIER)
+    for k in ("primary", "shadow", "hits"):
+        assert st[k] == ref.stats[k], k
+    assert st["hits"] > 0.2 * st["primary"]
+    assert np.array_equal(rgb, ref.rgb) and np.array_equal(plain, ref.rgb)
+    assert_ulp(linear, ref.linear, 0)
+    assert_ulp(plain_linear, ref.linear, 0)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_hierarchical_traversal_random_scenes(oracle, host, H, seed):
     """random_scene: shared subtrees under two parents (instancing), nested transformed groups, mirrors, glass, meshes,
