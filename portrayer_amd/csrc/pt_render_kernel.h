@@ -288,10 +288,14 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 // the occupancy query for this kernel with its LDS. The raised LDS limit and the occupancy are properties of (kernel, device):
 // kept per device, so that one process can drive several GPUs (pt_node).
 #define PT_MAX_DEVICES 64
-template <class Kernel>
-static hipError_t pt_launch_kernel(Kernel kernel, size_t lds, const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
+// KERNEL is a non-type template parameter: every kernel instantiation gets its own `state` (templated on the kernel's TYPE - void(*)(PtRenderArgs)
+// for all of them - one array was shared by all kernels of a translation unit, and a kernel inherited the occupancy and the raised LDS limit of
+// whichever kernel with the same LDS size had been launched first: ADVICE r03).
+template <auto KERNEL>
+static hipError_t pt_launch_kernel(size_t lds, const PtRenderArgs& a, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
+    constexpr auto kernel = KERNEL;
     struct PerDevice { size_t lds_allowed = 64 * 1024; size_t occ_lds = ~(size_t)0; int per_cu = 0; };
-    static PerDevice state[PT_MAX_DEVICES];  // one per instantiation (this function is a template) and device
+    static PerDevice state[PT_MAX_DEVICES];  // one per kernel instantiation and device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -331,25 +335,25 @@ template <int MODE, bool STATS, bool TEX>
 static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_mode, int n_cu, hipStream_t stream, uint32_t* grid_out, bool launch) {
     const size_t lds = pt_render_lds_bytes(a.stack_lds_cap, TEX, (variant == PT_RUN_INTERP_PARK || variant == PT_RUN_INTERP_FORK) ? 1 : 0);
     switch (variant) {
-    case PT_RUN_INTERP_PARK: return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 1>, lds, a, n_cu, stream, grid_out, launch);
-    case PT_RUN_INTERP_FORK: return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 3>, lds, a, n_cu, stream, grid_out, launch);
-    case PT_RUN_INTERP: return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_INTERP_PARK: return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 1>>(lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_INTERP_FORK: return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 3>>(lds, a, n_cu, stream, grid_out, launch);
+    case PT_RUN_INTERP: return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 0>>(lds, a, n_cu, stream, grid_out, launch);
 #ifdef PT_KEEP_INTERP
     case PT_RUN_INTERP4:
-        if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 2>, lds, a, n_cu, stream, grid_out, launch);
-        return pt_launch_kernel(&pt_render_kernel<MODE, STATS, TEX, 0>, lds, a, n_cu, stream, grid_out, launch);
+        if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 2>>(lds, a, n_cu, stream, grid_out, launch);
+        return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 0>>(lds, a, n_cu, stream, grid_out, launch);
 #endif
     case PT_RUN_CHAIN:
         if constexpr (MODE != PT_MODE_KD)
-            if (a.four_waves == 4) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 4, true>, lds, a, n_cu, stream, grid_out, launch);
-        return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 3, true>, lds, a, n_cu, stream, grid_out, launch);
+            if (a.four_waves == 4) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 4, true>>(lds, a, n_cu, stream, grid_out, launch);
+        return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 3, true>>(lds, a, n_cu, stream, grid_out, launch);
     case PT_RUN_LINE5:  // mesh-free scenes in the flat_scene / hierarchical semantics: 96 registers, 5 waves per SIMD
-        if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>, lds, a, n_cu, stream, grid_out, launch);
+        if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>>(lds, a, n_cu, stream, grid_out, launch);
         [[fallthrough]];
     case PT_RUN_LINE4:  // the k-d tree semantics with mesh instances (per-lane walk through two levels of trees) have no 4-wave instantiation
-        if constexpr (MODE != PT_MODE_KD) return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 4>, lds, a, n_cu, stream, grid_out, launch);
+        if constexpr (MODE != PT_MODE_KD) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 4>>(lds, a, n_cu, stream, grid_out, launch);
         [[fallthrough]];
-    default: return pt_launch_kernel(&pt_render_simple_kernel<MODE, STATS, TEX, 3>, lds, a, n_cu, stream, grid_out, launch);
+    default: return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 3>>(lds, a, n_cu, stream, grid_out, launch);
     }
 }
 

@@ -1039,7 +1039,12 @@ PT_HD PtRayPk pt_raypk(const PtRay& r, bool lanes, int* oct) {
     const bool nx = PT_BALLOT(lanes && sx == 2) != 0ull, px = PT_BALLOT(lanes && sx == 1) != 0ull;
     const bool ny = PT_BALLOT(lanes && sy == 2) != 0ull, py = PT_BALLOT(lanes && sy == 1) != 0ull;
     const bool nz = PT_BALLOT(lanes && sz == 2) != 0ull, pz = PT_BALLOT(lanes && sz == 1) != 0ull;
-    *oct = ((nx && px) || (ny && py) || (nz && pz)) ? PT_OCT_MIXED : ((nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0));
+    // A lane with a switched-off axis holds A = (0, -inf), B = (0, +inf) there: "entering through the lower plane". Under an octant
+    // whose bit for that axis is set pt_slab_pk2 would read B as the entering value (+inf) and reject every box for that lane - its ray
+    // would silently miss the scene (level cameras with centre sampling: a whole row / column of pixels). Such a wavefront takes the
+    // per-lane form, where min / max sort the pair whatever the octant.
+    const bool off = PT_BALLOT(lanes && (sx == 0 || sy == 0 || sz == 0)) != 0ull;
+    *oct = (off || (nx && px) || (ny && py) || (nz && pz)) ? PT_OCT_MIXED : ((nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0));
     return q;
 }
 PT_HD pt_f32x2 pt_pair_f32(uint32_t a, uint32_t b) { pt_f32x2 v; v.x = pt_f32_of(a); v.y = pt_f32_of(b); return v; }

@@ -518,6 +518,37 @@ def test_hierarchical_rays_with_negative_zero_components(oracle, host, H):
         assert_ulp(linear, ref.linear, 0)
 
 
+@pytest.mark.parametrize("size", [(129, 97), (31, 47), (33, 15), (47, 31), (15, 33), (64, 64)])
+@pytest.mark.parametrize("mode", ["flat", "hier", "kd"])
+def test_rays_parallel_to_an_axis_on_the_plain_kernels(oracle, host, H, size, mode):
+    """a ray with a direction component of exactly 0 has that axis of the slab test switched off - A = (0, -inf),
+    B = (0, +inf) - and the per-octant tree step read B as the entering value whenever OTHER lanes of the wavefront were negative on that
+    axis: the ray missed the whole scene. Only the PLAIN kernels compile the per-octant steps (the counting build always takes the per-lane
+    form), so this renders without stats: a level, axis-aligned camera with centre samples, sizes whose centre row / column is the first
+    or last of its 8x8 tile (16 m + 1, 16 m + 15) and sizes where it is not; mesh-free (modes 3 / 6 / 7), image and f64 means == oracle."""
+    mats = [Material(diffuse=(0.7, 0.4, 0.2), specular=(0.3, 0.3, 0.3), shininess=25.0), Material(diffuse=(0.2, 0.5, 0.8), specular=(0.2, 0.2, 0.2), shininess=10.0)]
+    kids = [Node.geo(Plane(), mats[0]).scaled(12.0).translated((0.0, -1.0, 0.0)),
+            Node.geo(Sphere(), mats[1]).translated((0.0, 0.0, 0.0)),
+            Node.group([Node.geo(Cube(), mats[1]).scaled(0.8).translated((0.0, 1.6, 0.0))]),
+            Node.geo(Cone(), mats[0]).translated((-2.0, 0.0, 0.5)),
+            Node.group([Node.geo(Cylinder(), mats[0])]).translated((2.0, 0.0, 0.5))]
+    scene = Scene(root=Node.group(kids), lights=[Light(position=(0.0, 6.0, 0.0), color=(0.9, 0.9, 0.9)), Light(position=(-3.0, 2.0, 7.0), color=(0.4, 0.4, 0.4))],
+                  ambient=(0.2, 0.2, 0.2))
+    cam = Camera(eye=(0.0, 0.0, 9.0), center=(0.0, 0.0, 0.0), fovy_degrees=40.0)   # level: the centre row has d.y == 0, the centre column d.x == 0
+    w, h = size
+    bg = default_background(w, h)
+    tr, om = {"flat": (H.TRAVERSE_FLAT, oracle.MODE_FLAT), "hier": (H.TRAVERSE_HIER, oracle.MODE_HIER), "kd": (H.TRAVERSE_KD, oracle.MODE_KD)}[mode]
+    r = host.Renderer(host_glue.host_scene(scene), tr, kd_depth=4)
+    for kw in ({}, dict(samples=4, seed=3, sample_mode=H.SAMPLE_RNG)):
+        rgb, linear, st = r.render(host_glue.cam10(cam), w, h, bg, **kw)
+        assert not st["kernel_variant"] & H.KERNEL_COUNTING
+        ref = oracle.render(oracle.pack(scene), cam, w, h, mode=om, kd_depth=4,
+                            **({"samples": 4, "seed": 3, "jitter": oracle.JITTER_RNG} if kw else {}))
+        assert np.array_equal(rgb, ref.rgb), (size, mode, kw)
+        assert_ulp(linear, ref.linear, 0)
+    r.close()
+
+
 @pytest.mark.parametrize("with_mesh", [False, True])
 def test_hierarchical_paths_longer_than_the_record(oracle, host, H, with_mesh):
     """A flattened node's path record (hier_rec) holds seven levels; deeper paths fall back to the chain arrays - in the wave-uniform
