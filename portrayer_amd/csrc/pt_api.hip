@@ -176,7 +176,7 @@ struct pt_context {
     std::string err;
     PtBuf inv, fwd, nrm, info, tri_v, tri_n, meshes, materials, lights, bvh, bvh4, bvh_items, kd, kd_items;
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, texview, mkd, mkd_items;
-    PtBuf node_box, kd_box, mkd_box, mkd_item_box;
+    PtBuf node_box, kd_box, mkd_box, mkd_item_box, kd_ref;
     PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank, hier_rec;  // PT_TRAVERSE_HIER: the scene graph
     PtBuf spill, stack_spill, accum, bg, rgb, linear, misc;  // misc: work counter + overflow flag (8 B), PtCounters at +256
     bool needs_spill = false;  // some material is reflective (recursion frames) or the scene has more than 32 lights
@@ -252,7 +252,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank, &c->hier_rec};
+                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->kd_ref, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank, &c->hier_rec};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -615,6 +615,29 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
                 node_box32[6 * j + 3 + k] = pt_bvh_detail::round_up(node_box[kdi[j]].hi[k]);
             }
     }
+    // the wave-uniform k-d walk (pt_trace_packet_kd) reads a leaf reference and its cull box in ONE scalar fetch: 32 bytes {node, 0, box}
+    std::vector<uint32_t> kd_ref32;
+    int kd_levels = 0;  // split levels on the deepest path of the tree (root = level 0)
+    if (traverse == PT_TRAVERSE_KD) {
+        kd_ref32.resize(8 * kdi.size());
+        for (size_t j = 0; j < kdi.size(); j++) {
+            kd_ref32[8 * j] = kdi[j]; kd_ref32[8 * j + 1] = 0u;
+            memcpy(&kd_ref32[8 * j + 2], &node_box32[6 * j], 6 * sizeof(float));
+        }
+        std::vector<std::pair<uint32_t, int>> todo;
+        std::vector<uint8_t> seen(kdn.size(), 0);
+        if (!kdn.empty()) todo.push_back({0u, 0});
+        while (!todo.empty()) {
+            auto [i, lev] = todo.back(); todo.pop_back();
+            if (seen[i]) return pt_fail(c, PT_ERR_ARGUMENT, "k-d tree is not a tree");
+            seen[i] = 1;
+            if (kdn[i].axis < 0) continue;
+            kd_levels = std::max(kd_levels, lev + 1);
+            todo.push_back({(uint32_t)kdn[i].front, lev + 1}); todo.push_back({(uint32_t)kdn[i].back, lev + 1});
+        }
+    }
+    if (kd_levels > PT_KD_WAVE_LEVELS)  // two bits of per-lane state per level in one 64-bit word (pt_trace_packet_kd); a tree that deep has > 2^32 leaves unless it is a degenerate chain
+        return pt_fail(c, PT_ERR_SCENE, "k-d tree deeper than 32 levels");
     std::vector<float> kd_box32;
     if (traverse == PT_TRAVERSE_KD) {  // children follow their parents in the linearised tree (pre-order): one backward sweep
         kd_box32.assign(6 * kdn.size(), 0.0f);
@@ -681,7 +704,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     if ((rc = pt_upload(c, c->inv, inv)) || (rc = pt_upload(c, c->fwd, fwd)) || (rc = pt_upload(c, c->nrm, nrm)) ||
         (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
         (rc = pt_upload(c, c->meshes, meshes)) || (rc = pt_upload(c, c->node_box, node_box32)) || (rc = pt_upload(c, c->kd_box, kd_box32)) ||
-        (rc = pt_upload(c, c->kd, kdn)) || (rc = pt_upload(c, c->kd_items, kdi)) || (rc = pt_upload(c, c->mkd, mkd)) ||
+        (rc = pt_upload(c, c->kd, kdn)) || (rc = pt_upload(c, c->kd_items, kdi)) || (rc = pt_upload(c, c->kd_ref, kd_ref32)) || (rc = pt_upload(c, c->mkd, mkd)) ||
         (rc = pt_upload(c, c->mkd_items, mkd_items)) || (rc = pt_upload(c, c->mkd_box, mkd_box)) || (rc = pt_upload(c, c->mkd_item_box, mkd_item_box)))
         return rc;
     std::vector<double> mats(s->materials, s->materials + 10 * (size_t)s->n_materials);
@@ -801,10 +824,11 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.tlas_root = tlas.child; v.tlas_direct = tlas_direct ? 1u : 0u;
     v.kd = (const PtKdNode*)c->kd.p; v.kd_items = (const uint32_t*)c->kd_items.p;
     v.kd_extent = kd_extent;
+    v.kd_ref = (const uint32_t*)c->kd_ref.p; v.kd_levels = kd_levels;
     v.node_box = traverse == PT_TRAVERSE_KD && !kdi.empty() ? (const float*)c->node_box.p : nullptr;
     v.kd_box = traverse == PT_TRAVERSE_KD ? (const float*)c->kd_box.p : nullptr;
     if (getenv("PORTRAYER_KD_NO_CULL")) v.kd_box = v.node_box = nullptr;  // experiment: the reference's walk as it is
-    v.mkd = (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;
+    v.mkd = mkd.empty() ? nullptr : (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;  // (null without KDMesh trees: the k-d walk then keeps no LDS rows for lane stacks)
     v.mkd_box = mkd_box.empty() || getenv("PORTRAYER_KD_NO_CULL") ? nullptr : (const float*)c->mkd_box.p;
     v.mkd_item_box = v.mkd_box ? (const float*)c->mkd_item_box.p : nullptr;
     v.mode = traverse == PT_TRAVERSE_KD ? (s->n_meshes == 0 ? PT_MODE_KD_NOMESH : PT_MODE_KD) : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
@@ -1042,7 +1066,9 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     if ((rc = pt_reserve(c, c->spill, spill_bytes))) return rc;
     // + wave_rows: the wavefront's own stack takes LDS rows from the lanes' stacks (pt_wave_rows, pt_render_simple.h): eight, or what a deep tree needs
     const int wave_rows = std::min(std::max(8, (a.scene.stack_cap + 63) / 64), std::max(a.stack_lds_cap, 8));  // (pt_wave_rows: at most this many)
-    if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * (size_t)std::max(a.scene.stack_cap - a.stack_lds_cap + wave_rows, 0) * 4))) return rc;
+    const int stack_spill_entries = std::max(a.scene.stack_cap - a.stack_lds_cap + wave_rows, 0);
+    a.kd_sav_offset = (uint32_t)std::max(stack_spill_entries, a.scene.stack_cap);  // behind everything a lane's own stack can reach (pt_trace_wave gives the lanes fewer LDS rows in the k-d semantics)
+    if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * ((size_t)a.kd_sav_offset + (kd_mode ? 2 * (size_t)std::max(a.scene.kd_levels, 0) : 0)) * 4))) return rc;
     if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4))) return rc;
     if ((rc = pt_reserve(c, c->accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
     a.accum = (double*)c->accum.p;
@@ -1089,6 +1115,7 @@ static int pt_collect_stats(pt_context* c, pt_stats* st, bool counted) {
         st->kernel_mode = c->last_mode; st->kernel_variant = c->last_variant;
     }
     if (head[1] & 2u) return pt_fail(c, PT_ERR_TRAVERSAL, "fork / join of refracted subtrees stalled (a lane waited for a colour nobody was computing): results invalid");
+    if (head[1] & 4u) return pt_fail(c, PT_ERR_TRAVERSAL, "a tree walk did not end (watchdog): results invalid");
     if (head[1]) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
     return PT_OK;
 }
@@ -1325,6 +1352,7 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     PT_HIP(c, hipMemcpy(out_sub, d_s, n * 4, hipMemcpyDeviceToHost));
     unsigned int head[2] = {0, 0};
     PT_HIP(c, hipMemcpy(head, c->misc.p, sizeof head, hipMemcpyDeviceToHost));
+    if (head[1] & 4u) return pt_fail(c, PT_ERR_TRAVERSAL, "a tree walk did not end (watchdog): results invalid");
     if (head[1]) return pt_fail(c, PT_ERR_TRAVERSAL, "traversal stack overflow");
     return PT_OK;
 }

@@ -63,6 +63,29 @@ PT_HD int pt_wave_rows(const PtRenderArgs& a) {
     return rows;
 }
 
+// The block's LDS stack area in the k-d tree semantics (one walk per wavefront, pt_trace_packet_kd): `lane_rows` rows (PT_BLOCK words each)
+// of per-lane stack columns - only scenes with KDMesh trees have any (pt_kdmesh_hit) -, then per wavefront `wrows` rows of 64 words:
+// `srows` for its stack (a word per pending split + what a mesh's triangle tree can have pending), the rest two rows per tree level for
+// the lanes' saved range bounds - the deepest levels; the top ones, touched once or twice per ray, in the lanes' HBM columns.
+struct PtKdLayout { int lane_rows, wrows, srows, lds_levels; };
+template <int MODE>
+PT_HD PtKdLayout pt_kd_layout(const PtRenderArgs& a) {
+    PtKdLayout l;
+    const int cap = a.stack_lds_cap;
+    l.srows = (a.scene.stack_cap + 63) / 64;
+    l.lane_rows = 0;
+    if (MODE == PT_MODE_KD && a.scene.mkd) {
+        int r = cap - l.srows - 2 * a.scene.kd_levels;
+        r = r < 2 ? 2 : r;
+        r = r > cap - l.srows ? cap - l.srows : r;
+        l.lane_rows = r < 0 ? 0 : r;
+    }
+    l.wrows = cap - l.lane_rows;  // >= 1
+    int lv = (l.wrows - l.srows) / 2;
+    l.lds_levels = lv < 0 ? 0 : (lv > a.scene.kd_levels ? a.scene.kd_levels : lv);
+    return l;
+}
+
 // One ray kind for the whole wavefront: `tracing` lanes carry `ray`; result in `hit` (untouched for the other lanes).
 template <int MODE, bool STATS>
 PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, bool any, PtHit& hit, const PtStackSpill& stk, uint32_t* lds, PtCounters* cnt) {
@@ -93,9 +116,22 @@ PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, 
         lane_stk.cap = a.stack_lds_cap - rows;
         pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, ray, tracing, any, hit, lds + (size_t)lane_stk.cap * PT_BLOCK + (size_t)wave * rows * 64, rows * 64, lane_stk,
                                                                 a.overflow_flag, cnt);
-    } else
-#endif
+    } else if (MODE == PT_MODE_KD_NOMESH || MODE == PT_MODE_KD) {  // (pt_scene_upload refuses trees of more than PT_KD_WAVE_LEVELS levels)
+        const PtKdLayout kl = pt_kd_layout<MODE>(a);
+        const int lane_rows = kl.lane_rows, wrows = kl.wrows, srows = kl.srows, lds_levels = kl.lds_levels;
+        PtStackSpill lane_stk = stk;
+        lane_stk.cap = lane_rows;
+        uint32_t* wbase = lds + (size_t)lane_rows * PT_BLOCK + (size_t)wave * wrows * 64;
+        PtKdSav sav;
+        sav.lds = wbase + (size_t)srows * 64;
+        sav.hbm_levels = a.scene.kd_levels - lds_levels;
+        sav.hbm = stk.gbase + (size_t)a.kd_sav_offset * stk.gstride;
+        sav.hbm_stride = stk.gstride;
+        pt_trace_packet_kd<STATS, MODE == PT_MODE_KD, MODE == PT_MODE_KD>(a.scene, ray, tracing, any, hit, wbase, (wrows < srows ? wrows : srows) * 64, sav, lane_stk, a.overflow_flag, cnt);
+    }
+#else
     if (tracing) pt_trace<MODE, STATS>(a.scene, ray, any, hit, stk, cnt);
+#endif
 }
 
 // The first words of the wavefront's own traversal stack (free between walks): the queue through which offered rays find takers
@@ -111,7 +147,7 @@ PT_HD uint32_t* pt_fork_queue(const PtRenderArgs& a, uint32_t* lds) {
         const int rows = pt_wave_rows(a);
         return lds + (size_t)(a.stack_lds_cap - rows) * PT_BLOCK + (size_t)wave * rows * 64;
     }
-    if (MODE == PT_MODE_KD || MODE == PT_MODE_KD_NOMESH) return lds + (size_t)(a.stack_lds_cap - 1) * PT_BLOCK + (size_t)wave * 64;  // the lanes' last row (per-lane walks: free between them too)
+    if (MODE == PT_MODE_KD || MODE == PT_MODE_KD_NOMESH) { const PtKdLayout kl = pt_kd_layout<MODE>(a); return lds + (size_t)kl.lane_rows * PT_BLOCK + (size_t)wave * kl.wrows * 64; }  // the first row of the wavefront's region: its stack, free between walks
     return lds + (size_t)wave * a.stack_lds_cap * 64;
 }
 
@@ -188,7 +224,7 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
 #endif
 #ifndef PT_NO_ARGS_AGAIN  // (shadows the kernel's own view of its arguments for the rest of the item. The k-d semantics of mesh-free scenes are as fast without
         // - 30.5 against 30.7 ms on big-scene, c22 / c50 -; with mesh instances they gain like the others: mirror 8.7 -> 9.6 Gray/s, macho-cows 6.7 -> 7.2, c50)
-        const PtRenderArgs& a = MODE == PT_MODE_KD_NOMESH ? a0 : pt_args_again(a0);
+        const PtRenderArgs& a = pt_args_again(a0);
         const PtSceneView& sc = a.scene;
 #endif
         // ---- the primary ray of this lane's sample (render.rs:36-41, camera.rs:48-84)

@@ -121,6 +121,8 @@ struct PtSceneView {
     const float* kd_box;     // KD mode: non-null = PtKdNode::box is valid and the walk culls with it (the array itself is a copy kept for tools); else null
     const float* node_box;   // KD mode: per kd_items entry, that node's padded world box as 6 f32 rounded outward (leaf pre-cull in pt_trace_kd); else null
     double kd_extent;  // bounding_box.rs:95-99: squared diagonal of the root bounds
+    const uint32_t* kd_ref;  // KD mode: per kd_items entry 8 words {flattened node, 0, its padded world box as 6 f32 rounded outward}: one scalar fetch per leaf reference (pt_trace_packet_kd)
+    int32_t kd_levels;       // KD mode: split levels on the deepest path of the scene's k-d tree
     int32_t mode;
     int32_t stack_cap;  // entries per lane in the traversal stack
     // texture.rs (all null when the scene has no textured material)

@@ -1508,6 +1508,348 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE walk per wavefront in the reference's k-d tree semantics (round 4; kdtree/node.rs:66-203).
+//
+// What the reference computes for a ray: the leaves on its path in front-to-back order, each with the range [start, end) the planes
+// of the straddled splits above it leave (node.rs:139-186), and the hit of the FIRST leaf that reports one (node.rs:153-157) - a
+// leaf's hit being the nearest in ITS range with the leaf's list order breaking exact ties (ray.rs:87-99). The ranges of a ray's
+// leaves are disjoint half-open intervals in path order, so "the first leaf with a hit" is "the leaf hit with the smallest t", and a
+// leaf's hit depends on nothing but the leaf and its range: the leaves of a ray may be visited in ANY order as long as each is
+// tested with the range the reference would give it. (Cone / Cylinder results depend on the range start - quirk Q1, cone.rs:64-76 -,
+// which is why the ranges must be the reference's own numbers: every plane parameter below is computed by the reference's
+// expression, (plane - o) / d in f64, from the reference's side tests.)
+//
+// That makes the walk a change of schedule like pt_trace_packet: the NODE and the stack are wave-uniform (a node = 64 bytes through
+// the scalar cache, planes and cull boxes as scalar operands), every lane carries its own (start, end), and a split sends each lane's
+// range where the reference sends it:
+//   * both ends of the lane's classification segment on one side (node.rs:128-137): that child, range unchanged;
+//   * straddling (node.rs:139-186): its near side gets [start, plane_t), its far side [plane_t, end);
+//   * plane_t outside the range (node.rs:146-147 panics): neither (counted as kd_plane_miss).
+// The wavefront enters the child most of its lanes call near first; the other waits on the wavefront's stack. Lanes skip nodes that
+// cannot improve their result (start > best.t: every hit below has t >= start).
+//
+// Where a lane's range lives: (start, end) of the CURRENT node in registers; entering a child replaces at most ONE bound by plane_t,
+// and the bound it replaces goes to the lane's slot of that LEVEL (`sav`: one f64 per lane and tree level - LDS for the deepest
+// levels, which the walk toggles between, HBM for the top ones). Two bits per level and lane (`codes`) say which bound the slot
+// holds: 2 = the END to put back, 3 = the START to put back, 1 = the lane waits for the second child with its range unchanged,
+// 0 = nothing. Popping the stack entry (second child of level L) puts back the bounds of the finished levels below L one by one,
+// then turns the first child's range into the second's: for a lane with [start, plane_t) the second child gets [plane_t, saved end),
+// and the slot now keeps `start` for the way back up; mirror-inverted for a lane that went far side first.
+// Nothing here is kept per stack ENTRY and lane (that would be 16 bytes x 64 lanes x depth of LDS per wavefront).
+// ------------------------------------------------------------------------------------------------
+struct PtKdSav {
+    uint32_t* lds;        // the wavefront's rows for saved bounds: slot j, half h of lane l at lds[(2 j + h) * 64 + l]
+    int hbm_levels;       // levels [0, hbm_levels) live in HBM, level k >= hbm_levels in LDS slot k - hbm_levels
+    uint32_t* hbm;        // this lane's column: half h of level k at hbm[(2 k + h) * hbm_stride]
+    uint32_t hbm_stride;
+};
+PT_HD void pt_kd_sav_store(const PtKdSav& s, int level, double v) {  // `level` is wave-uniform
+    union { double d; uint32_t u[2]; } c; c.d = v;
+    if (level >= s.hbm_levels) {
+        uint32_t* p = s.lds + (size_t)(2 * (level - s.hbm_levels)) * 64 + PT_LANE_ID();
+        p[0] = c.u[0]; p[64] = c.u[1];
+    } else {
+        uint32_t* p = s.hbm + (size_t)(2 * level) * s.hbm_stride;
+        p[0] = c.u[0]; p[s.hbm_stride] = c.u[1];
+    }
+}
+PT_HD double pt_kd_sav_load(const PtKdSav& s, int level) {
+    union { double d; uint32_t u[2]; } c;
+    if (level >= s.hbm_levels) {
+        const uint32_t* p = s.lds + (size_t)(2 * (level - s.hbm_levels)) * 64 + PT_LANE_ID();
+        c.u[0] = p[0]; c.u[1] = p[64];
+    } else {
+        const uint32_t* p = s.hbm + (size_t)(2 * level) * s.hbm_stride;
+        c.u[0] = p[0]; c.u[1] = p[s.hbm_stride];
+    }
+    return c.d;
+}
+#ifndef PT_KD_WALK_STEPS_MAX
+#define PT_KD_WALK_STEPS_MAX (1u << 26)  // more nodes than a k-d tree of 2^26 nodes (the limit of the 32-bit byte offsets) has
+#endif
+#define PT_KD_WAVE_LEVELS 32  // two bits per level in a 64-bit word per lane; deeper trees keep the per-lane walk (PtKdWalker)
+
+// Mesh::ray_hit below a k-d leaf (mesh.rs:146-167) for the lanes in `part`: the instance's triangle tree walked once per wavefront
+// like pt_trace_packet_mesh does, every triangle tested over [start, end of the lane's leaf fold) - nearest triangle, lowest index on
+// exact ties (pt_cand_end), which is what the reference's fold over ALL triangles with a shrinking range gives. `wstack`: free words
+// of the wavefront's stack. Returns false when they ran out.
+template <bool STATS>
+PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_t root, const PtRay& local, bool part, double start, bool any, PtHit& lb, bool& found,
+                                   uint32_t* wstack, int words, PtCounters* cnt) {
+    const PtRayPk q = pt_raypk(local);
+    float tm = pt_tmax32(lb.t);
+    unsigned long long pmask = PT_BALLOT(part);
+    uint32_t cur = root;
+    int sp = 0;
+    uint32_t steps = 0;  // (watchdog, as in pt_trace_packet_kd: leaves visited)
+    for (;;) {
+        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt);
+        steps++;
+        if (cur == PT_REF_EMPTY || steps > PT_KD_WALK_STEPS_MAX) return false;
+        if (cur != PT_REF_POP) {
+            const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+            if (STATS && part) cnt->n_leaf++;
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[first + i]);
+                const double* rec = sc.tri_v + 9 * (size_t)tri;
+                pt_u32x16 a;
+                uint32_t b0, b1;
+#if defined(__HIP_DEVICE_COMPILE__)
+                {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 b;
+                    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(rec)) : "memory");
+                    b0 = b[0]; b1 = b[1];
+                }
+#else
+                a = *reinterpret_cast<const pt_u32x16*>(rec);
+                b0 = reinterpret_cast<const uint32_t*>(rec)[16]; b1 = reinterpret_cast<const uint32_t*>(rec)[17];
+#endif
+                double tv[9];
+#pragma unroll
+                for (int k = 0; k < 8; k++) tv[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
+                tv[8] = pt_f64_of(b0, b1);
+                if (part) {
+                    double tt, beta, gamma;
+                    if (STATS) cnt->n_tri++;
+                    if (pt_triangle_hit(tv, local, start, pt_cand_end(lb, inst, tri), &tt, &beta, &gamma)) {
+                        lb.t = tt; lb.node = inst; lb.sub = tri;
+                        found = true;
+                        tm = pt_tmax32(tt);
+                        if (any) part = false;  // a shadow ray only asks whether anything is in the way (material.rs:174-179)
+                    }
+                }
+            }
+            pmask = PT_BALLOT(part);
+            if (!pmask) return true;
+        }
+        if (sp == 0) return true;
+        sp--;
+        cur = PT_UNIFORM_U32(wstack[sp]);
+    }
+}
+
+// wstack: the wavefront's own stack (linear, `wwords` words); sav: the lanes' saved bounds per level; lane_stk: the lanes' own stacks
+// (KDMESH only: KDMesh instances keep the reference's triangle k-d tree, which every lane walks by itself, pt_kdmesh_hit).
+template <bool STATS, bool MESH, bool KDMESH, class LaneStack>
+PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wwords, const PtKdSav& sav,
+                              const LaneStack& lane_stk, unsigned int* overflow, PtCounters* cnt) {
+    // (a copy: picking a component by the split's axis from a ray behind a REFERENCE becomes a load from a selected address, and the
+    // caller's ray then lives in scratch memory and is indexed there at every split)
+    const PtRay ray = ray_in;
+    if (has_ray) { best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0; }
+    const unsigned long long self = 1ull << PT_LANE_ID();
+    bool alive = has_ray;             // the lane still wants candidates (a shadow ray stops at its first hit)
+    double start = PT_EPSILON, end = INFINITY;  // ray.rs:140; the lane's range at the current node
+    unsigned long long codes = 0;     // two bits per level of the current path (see above)
+    const PtRayPk q = pt_raypk(ray);
+    const double extent = sc.kd_extent;
+    uint32_t cur = 0;                 // wave-uniform: node, its level, words on the stack, the lanes taking part in `cur`
+    int lev = 0, sp = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (pinned to scalar registers from the start: the constant 0 otherwise reaches the loop's phi as a copy of some VECTOR register that
+    // also holds a 0, and the compiler's SGPR-copy fixing then moves the whole chain - and the scalar load's offset - to the vector side)
+    asm volatile("" : "+s"(cur), "+s"(lev), "+s"(sp));
+#endif
+    unsigned long long in = PT_BALLOT(alive);
+    // ONE way out of the walk (the test at the bottom): an early `return` from inside these loops - with the lanes' divergent code of the
+    // failure path behind it - makes the compiler's unified loop exit a join of divergent branches, and every wave-uniform value that
+    // passes through it (the node index, the stack pointer, the lane masks) is then taken for divergent: no scalar loads, no SALU block.
+    bool failed = false;   // wave-uniform: the wavefront's stack overflowed, or the watchdog below tripped
+    uint32_t steps = 0;    // wave-uniform: nodes visited by this walk. A walk visits a node at most once; one that goes on beyond any tree this
+                           // library accepts is a defect (or a corrupted stack) and fails the render (PT_ERR_TRAVERSAL) instead of hanging the GPU
+    for (;;) {
+        steps++;
+        failed = failed || steps > PT_KD_WALK_STEPS_MAX;
+#ifdef PT_KD_DEBUG
+        if (STATS && steps > PT_KD_WALK_STEPS_MAX && PT_LANE_ID() == 0u) { cnt->diag[0] = cur; cnt->diag[1] = (unsigned long long)lev; cnt->diag[2] = (unsigned long long)sp; cnt->diag[3] = in; cnt->diag[4] = (unsigned long long)wwords; cnt->diag[5] = (unsigned long long)sav.hbm_levels; }
+#endif
+        bool descend = false;  // wave-uniform: go on with `cur` (a child) instead of taking the next pending subtree
+        // the lanes this node can still give something: taking part, and no hit yet in front of everything below (every hit
+        // below has t >= start, and ranges of different leaves never share a t)
+        bool mine = !failed && alive && (in & self) != 0ull && !(best.t < start);
+        if (PT_BALLOT(mine)) {
+            const pt_u32x16 v = pt_sload_node(sc.kd, cur);
+            PT_WAVE_COUNT(4);
+            // the lane's segment [start, end), rounded outward, against the conservative f32 bounds of everything below this node:
+            // a subtree the segment does not reach reports no hit, which is all the reference would find out by walking it
+            float seg0 = (float)start, seg1 = (float)end;
+            seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
+            if (sc.kd_box) {
+                const float lo[3] = {pt_f32_of(v[8]), pt_f32_of(v[9]), pt_f32_of(v[10])}, hi[3] = {pt_f32_of(v[11]), pt_f32_of(v[12]), pt_f32_of(v[13])};
+                const bool reach = pt_slab_seg_pk(lo, hi, q, seg0, seg1);
+                if (STATS && mine && !reach) cnt->kd_culled++;
+                mine = mine && reach;
+            }
+            const int axis = (int)v[2];
+            if (axis >= 0) {
+                // ---- a split (node.rs:112-202), for the lanes in `mine`
+                if (STATS && mine) cnt->n_inner++;
+                const double plane = pt_f64_of(v[0], v[1]);
+                double t_max = start + extent;                                   // node.rs:118
+                if (!pt_in_range(start, end, t_max)) t_max = end - PT_EPSILON;   // node.rs:121
+                const double t_min = start + PT_EPSILON;                         // node.rs:124
+                const double o = axis == 0 ? ray.o.x : (axis == 1 ? ray.o.y : ray.o.z), d = axis == 0 ? ray.d.x : (axis == 1 ? ray.d.y : ray.d.z);
+                const bool s = ((o + d * t_min) - plane) >= 0.0;                 // infinite_plane.rs:27-35
+                const bool e = ((o + d * t_max) - plane) >= 0.0;
+                const bool same = s == e;
+                double plane_t = 0.0;
+                bool strad = false;
+                if (PT_BALLOT(mine && !same)) {
+                    plane_t = (plane - o) / d;                                   // node.rs:90-109
+                    strad = mine && !same && pt_in_range(start, end, plane_t);
+                    if (STATS && mine && !same && !strad) cnt->kd_plane_miss++;  // node.rs:146-147 / :177-178: the reference panics here; a miss for this subtree
+                }
+                const bool go_f = mine && (same ? s : strad), go_b = mine && (same ? !s : strad);
+                const unsigned long long m_f = PT_BALLOT(go_f), m_b = PT_BALLOT(go_b);
+                // the child most lanes call near goes first (a lane's near side is the side of its range start)
+                const int n_f = __builtin_popcountll(PT_BALLOT((go_f || go_b) && s)), n_b = __builtin_popcountll(PT_BALLOT((go_f || go_b) && !s));
+                const bool front_first = n_f >= n_b;
+                const uint32_t c_first = front_first ? v[3] : v[4], c_second = front_first ? v[4] : v[3];
+                const unsigned long long m_first = front_first ? m_f : m_b, m_second = front_first ? m_b : m_f;
+                // (the wave-uniform bookkeeping in straight-line code, before the lanes' own: a uniform value that changed inside the
+                // lanes' branches below would meet them at one join and be taken for divergent as well)
+                const bool push = m_second != 0ull;
+                const bool room = sp + 2 <= wwords;
+                if (room) { wstack[sp] = c_second; wstack[sp + 1] = (uint32_t)lev; }  // (a free slot when nothing is pushed)
+                failed = failed || (push && !room);
+                descend = (m_f | m_b) != 0ull && !failed;
+                sp += (push && descend) ? 2 : 0;
+                uint32_t code = 0;
+                if (push && descend) {
+                    const bool in_first = front_first ? go_f : go_b, in_second = front_first ? go_b : go_f;
+                    if (in_first && in_second) {   // straddling: one bound becomes plane_t, the other side's comes from the slot later
+                        if (s == front_first) { pt_kd_sav_store(sav, lev, end); end = plane_t; code = 2u; }
+                        else { pt_kd_sav_store(sav, lev, start); start = plane_t; code = 3u; }
+                    } else if (in_second) {
+                        code = 1u;
+                    }
+                }
+                if (descend) {
+                    codes = (codes & ~(3ull << (2 * lev))) | ((unsigned long long)code << (2 * lev));
+                    in = m_first; cur = c_first; lev++;
+                }
+            } else if (PT_BALLOT(mine)) {
+                // ---- a leaf: ray.rs:87-99 fold over the leaf's nodes in the reference's order with a strictly shrinking end
+                if (STATS && mine) cnt->n_leaf++;
+                PT_WAVE_COUNT(5);
+                const uint32_t first = v[5], count = v[6];
+                PtHit lb; lb.t = end; lb.node = PT_NO_HIT; lb.sub = 0;
+                bool found = false;
+                bool want = mine;  // a shadow ray is done with its first hit
+                for (uint32_t i = 0; i < count; i++) {
+                    // the reference and its cull box in one scalar fetch: {flattened node, 0, the node's padded world box as 6 f32 rounded outward}
+                    const pt_u32x8 ref = pt_sload8(sc.kd_ref + 8 * (size_t)(first + i));
+                    const uint32_t item = ref[0];
+                    bool test = want;
+                    if (sc.node_box) {  // a node whose box the lane's segment does not reach cannot report a hit in it
+                        const float lo[3] = {pt_f32_of(ref[2]), pt_f32_of(ref[3]), pt_f32_of(ref[4])}, hi[3] = {pt_f32_of(ref[5]), pt_f32_of(ref[6]), pt_f32_of(ref[7])};
+                        if (STATS && want) cnt->n_bbox++;
+                        test = want && pt_slab_seg_pk(lo, hi, q, seg0, seg1);
+                    }
+                    if (!PT_BALLOT(test)) continue;
+                    // the node's record in one round trip through the scalar cache: {type, data, flags, material} and rows 0..2 of its inverse
+                    pt_u32x4 info;
+                    pt_u32x16 ma;
+                    pt_u32x8 mb;
+                    const void* info_ptr = sc.info + 4 * (size_t)item;
+                    const void* rec = sc.inv + 12 * (size_t)item;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&s"(info), "=&s"(ma), "=&s"(mb) : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(rec)) : "memory");
+#else
+                    info = *static_cast<const pt_u32x4*>(info_ptr);
+                    ma = *static_cast<const pt_u32x16*>(rec);
+                    mb = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(rec) + 64);
+#endif
+                    const uint32_t type = info[0], data = info[1];
+                    double mm[12];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) mm[k] = pt_f64_of(ma[2 * k], ma[2 * k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) mm[8 + k] = pt_f64_of(mb[2 * k], mb[2 * k + 1]);
+                    const PtRay local = pt_ray_to_local(mm, ray);  // flat_scene.rs:74
+                    if (STATS && test) cnt->n_analytic++;
+                    bool hit = false;
+                    if (MESH && (type == PT_MESH || type == PT_KDMESH)) {
+                        const PtMeshInfo* mi = sc.meshes + data;
+                        if (KDMESH && type == PT_KDMESH && (int32_t)PT_UNIFORM_U32((uint32_t)mi->kd_root) >= 0) {  // the reference's own triangle tree (quirk Q3), per lane
+                            if (test) {
+                                double t; uint32_t tri = 0;
+                                if (pt_kdmesh_hit<STATS>(sc, *mi, local, start, pt_cand_end(lb, item, 0), lane_stk, 0, &t, &tri, cnt)) { lb.t = t; lb.node = item; lb.sub = tri; hit = true; }
+                            }
+                        } else {  // mesh.rs:146-155: box test, then the triangles (also a KDMesh without a tree of its own: PORTRAYER_KDMESH_AS_MESH)
+                            const uint32_t root = PT_UNIFORM_U32(mi->blas_root);
+                            if (STATS && test) cnt->n_bbox++;
+                            if (root == PT_REF_EMPTY) continue;
+                            double bi[12];
+                            pt_sload_mat12(mi->bbox_inv, bi);
+                            const bool inside = test && pt_bbox_test_hit(bi, local, start, pt_cand_end(lb, item, 0));
+                            if (!PT_BALLOT(inside)) continue;
+                            if (!pt_packet_mesh_below_kd<STATS>(sc, item, root, local, inside, start, any, lb, hit, wstack + sp, wwords - sp, cnt)) failed = true;
+                        }
+                    } else if (test) {
+                        double t; uint32_t part = 0;
+                        if (type == PT_TRIANGLE) {  // stand-alone triangle, stored after the mesh triangles
+                            double beta, gamma;
+                            if (STATS) cnt->n_tri++;
+                            hit = pt_triangle_hit(sc.tri_v + 9 * (size_t)data, local, start, pt_cand_end(lb, item, data), &t, &beta, &gamma);
+                            part = data;
+                        } else {
+                            hit = pt_unit_prim_hit(type, local, start, pt_cand_end(lb, item, 0), &t, &part);
+                        }
+                        if (hit) { lb.t = t; lb.node = item; lb.sub = part; }
+                    }
+                    if (hit) {
+                        found = true;
+                        if (any) want = false;
+                        // the segment has shrunk: later references of this leaf are culled against the new end
+                        seg1 = (float)lb.t; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
+                    }
+                }
+                if (found) {  // (start <= lb.t < best.t by the admission test above)
+                    best = lb;
+                    if (any) alive = false;
+                }
+            }
+        }
+        if (descend) continue;
+        // ---- the next pending subtree: the second child of the split at level L
+        if (failed || !PT_BALLOT(alive) || sp == 0) break;
+        sp -= 2;
+        cur = PT_UNIFORM_U32(wstack[sp]);
+        const int L = (int)PT_UNIFORM_U32(wstack[sp + 1]);
+        for (int k = lev - 1; k > L; k--) {  // the finished levels below it: put the replaced bounds back
+            const uint32_t c = (uint32_t)(codes >> (2 * k)) & 3u;
+            if (PT_BALLOT(c >= 2u)) {
+                if (c >= 2u) {
+                    const double sv = pt_kd_sav_load(sav, k);
+                    if (c == 2u) end = sv; else start = sv;
+                }
+            }
+        }
+        {
+            const uint32_t c = (uint32_t)(codes >> (2 * L)) & 3u;
+            uint32_t c2 = 0u;
+            if (PT_BALLOT(c >= 2u)) {
+                if (c == 2u) { const double pt = end; end = pt_kd_sav_load(sav, L); pt_kd_sav_store(sav, L, start); start = pt; c2 = 3u; }        // had [start, plane_t): now [plane_t, end)
+                else if (c == 3u) { const double pt = start; start = pt_kd_sav_load(sav, L); pt_kd_sav_store(sav, L, end); end = pt; c2 = 2u; }  // had [plane_t, end): now [start, plane_t)
+            }
+            in = PT_BALLOT(c != 0u);
+            codes = (codes & ~(3ull << (2 * L))) | ((unsigned long long)c2 << (2 * L));
+        }
+        lev = L + 1;
+    }
+    if (failed) {  // never expected (pt_scene_upload sizes the stack); recorded unconditionally so that a render whose results would be wrong cannot return PT_OK
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (overflow) atomicOr(overflow, steps > PT_KD_WALK_STEPS_MAX ? 4u : 1u);  // 4: the watchdog
+#endif
+        if (STATS) cnt->stack_overflow++;
+        if (has_ray) best.node = PT_NO_HIT;
+    }
+}
+
 // Traversal of one ray in the semantics of `MODE` (PT_MODE_*).
 template <int MODE, bool STATS, class Stack>
 PT_HD void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const Stack& stk, PtCounters* cnt) {

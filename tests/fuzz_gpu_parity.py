@@ -44,12 +44,16 @@ def extreme_scene(seed):
     return Scene(root=Node.group(kids), lights=lights, ambient=(0.2, 0.2, 0.2)), Camera(eye=(1.0, 2.5, 9.0), center=(0.0, 0.0, 0.0), fovy_degrees=45.0)
 
 
+MODES = os.environ.get("FUZZ_MODES", "flat,kd,hier").split(",")  # FUZZ_MODES=kd: only the k-d tree semantics
+
+
 def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
     w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (128, 96)
     samples = int(sys.argv[5]) if len(sys.argv) > 5 else 2  # 2: 32 pixels x 2 samples per wavefront; 32: 2 pixels x 4 chunks x 8; 64: one pixel
     bad_total = 0
     tex_edge = 0
+    n_renders = 0
     for seed in range(first, first + count):
         from test_gpu_textures import textured_scene  # random texels, normal maps, uv transforms on every primitive kind
         for kind, make in (("random", random_scene), ("extreme", extreme_scene), ("textured", textured_scene), ("analytic", analytic_scene),
@@ -58,6 +62,9 @@ def main():
             ps = O.pack(scene)
             hs = host_glue.host_scene(scene)
             for mode, tr, om in (("flat", H.TRAVERSE_FLAT, O.MODE_FLAT), ("kd", H.TRAVERSE_KD, O.MODE_KD), ("hier", H.TRAVERSE_HIER, O.MODE_HIER)):
+                if mode not in MODES:
+                    continue
+                n_renders += 1
                 r = host.Renderer(hs, tr, kd_depth=8)
                 rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=samples, seed=seed, sample_mode=H.SAMPLE_RNG, stats=True)
                 ref = O.render(ps, cam, w, h, samples=samples, seed=seed, jitter=O.JITTER_RNG, mode=om, kd_depth=8)
@@ -78,7 +85,7 @@ def main():
                     print(f"MISMATCH seed {seed} {kind} {mode}: {int(bad.sum())} pixels, rays_equal={rays_equal}, first {np.argwhere(bad)[:4].tolist()}, "
                           f"kd_plane_miss gpu {st['kd_plane_miss']} oracle {ref.stats['kd_plane_miss']}", flush=True)
                 r.close()
-    print(f"fuzz done: seeds {first}..{first + count - 1} ({15 * count} renders, {w}x{h}x{samples}), {bad_total} differing pixels in total ({tex_edge} texel-edge pixels in textured scenes tolerated)")
+    print(f"fuzz done: seeds {first}..{first + count - 1} ({n_renders} scenes x modes, each the counting and the plain instantiation, {w}x{h}x{samples}), {bad_total} differing pixels in total ({tex_edge} texel-edge pixels in textured scenes tolerated)")
 
 
 if __name__ == "__main__":
