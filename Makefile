@@ -28,7 +28,7 @@ examples/bin/%: examples/%.cpp portrayer_amd/libportrayer_host.so
 # traversal mode (one source, six objects) - compiled side by side under make -j.
 OBJDIR ?= $(CSRC)
 HIPLIB ?= portrayer_amd/libportrayer_hip.so
-RENDER_MODES := 1 2 3 4 5 6 7 8
+RENDER_MODES := 1 2 3 4 5 6 7 8 9
 HIP_OBJS := $(OBJDIR)/pt_api.o $(OBJDIR)/pt_build.o $(OBJDIR)/pt_node.o $(foreach m,$(RENDER_MODES),$(OBJDIR)/pt_render_m$(m).o)
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDRS)

@@ -187,7 +187,8 @@ typedef struct {
 /* pt_stats.kernel_mode: the walk the kernel was compiled with */
 enum { PT_KERNEL_MODE_FLAT = 1, PT_KERNEL_MODE_KD = 2, PT_KERNEL_MODE_FLAT_NOMESH = 3, PT_KERNEL_MODE_FLAT_KDMESH = 4, PT_KERNEL_MODE_HIER = 5,
        PT_KERNEL_MODE_HIER_NOMESH = 6, PT_KERNEL_MODE_KD_NOMESH = 7,
-       PT_KERNEL_MODE_HIER_MESH = 8 /* hierarchical, Mesh instances but no KDMesh trees (5 has both compiled in) */ };
+       PT_KERNEL_MODE_HIER_MESH = 8 /* hierarchical, Mesh instances but no KDMesh trees (5 has both compiled in) */,
+       PT_KERNEL_MODE_KD_MESH = 9 /* kdtree semantics, Mesh instances but no KDMesh trees (2 has both compiled in) */ };
 /* pt_stats.kernel_variant: bit 0-3 waves per SIMD the kernel was compiled for (3 or 4); PT_KERNEL_INTERPRETER: the per-lane
  * interpreter that scenes with reflective materials need (material.rs:216-303), else the straight-line kernel; PT_KERNEL_PARK:
  * a parked recursion frame per lane in LDS; PT_KERNEL_COUNTING: the counting build (collect_stats); PT_KERNEL_TEXTURED */

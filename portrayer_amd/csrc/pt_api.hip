@@ -53,6 +53,9 @@ __global__ void pt_math_kernel(int op, uint64_t n, const double* a, const double
     case 4: r = atan2(a[i], b[i]); break;   // sphere.rs:57-58 (texture coordinates)
     case 5: r = acos(a[i]); break;          // sphere.rs:59
     case 6: r = pow(a[i], b[i]); break;     // the device library's pow, for comparison
+    case 7:  // the k-d walk's short division (pt_trace.h: pt_div_fast) where its exponent test admits the operands, NaN where it does not
+        r = (pt_div_exp_ok(a[i]) && pt_div_exp_ok(b[i])) ? pt_div_fast(a[i], b[i], pt_rcp_refined(b[i])) : __builtin_nan("");
+        break;
     default: r = 0.0; break;
     }
     out[i] = r;
@@ -828,10 +831,11 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     v.node_box = traverse == PT_TRAVERSE_KD && !kdi.empty() ? (const float*)c->node_box.p : nullptr;
     v.kd_box = traverse == PT_TRAVERSE_KD ? (const float*)c->kd_box.p : nullptr;
     if (getenv("PORTRAYER_KD_NO_CULL")) v.kd_box = v.node_box = nullptr;  // experiment: the reference's walk as it is
+    if (const char* e = getenv("PORTRAYER_KD_CULL")) { const int m = atoi(e); if (!(m & 1)) v.kd_box = nullptr; if (!(m & 2)) v.node_box = nullptr; }  // experiment: bit 0 tree nodes, bit 1 leaf references
     v.mkd = mkd.empty() ? nullptr : (const PtKdNode*)c->mkd.p; v.mkd_items = (const uint32_t*)c->mkd_items.p;  // (null without KDMesh trees: the k-d walk then keeps no LDS rows for lane stacks)
     v.mkd_box = mkd_box.empty() || getenv("PORTRAYER_KD_NO_CULL") ? nullptr : (const float*)c->mkd_box.p;
     v.mkd_item_box = v.mkd_box ? (const float*)c->mkd_item_box.p : nullptr;
-    v.mode = traverse == PT_TRAVERSE_KD ? (s->n_meshes == 0 ? PT_MODE_KD_NOMESH : PT_MODE_KD) : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
+    v.mode = traverse == PT_TRAVERSE_KD ? (s->n_meshes == 0 ? PT_MODE_KD_NOMESH : (any_kdmesh ? PT_MODE_KD : PT_MODE_KD_MESH)) : (s->n_meshes == 0 ? PT_MODE_FLAT_NOMESH : (any_kdmesh ? PT_MODE_FLAT_KDMESH : PT_MODE_FLAT));
     if (traverse == PT_TRAVERSE_HIER) {  // the general walker (meshes and KDMesh trees compiled in), or its mesh-free instantiation
         v.mode = s->n_meshes == 0 ? PT_MODE_HIER_NOMESH : (any_kdmesh ? PT_MODE_HIER : PT_MODE_HIER_MESH);
         v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
@@ -903,6 +907,7 @@ static hipError_t pt_dispatch(const PtRenderArgs& a, bool stats, int n_cu, hipSt
     case PT_MODE_HIER_NOMESH: return pt_launch_mode_6(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     case PT_MODE_KD_NOMESH: return pt_launch_mode_7(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     case PT_MODE_HIER_MESH: return pt_launch_mode_8(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
+    case PT_MODE_KD_MESH: return pt_launch_mode_9(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     default: return pt_launch_mode_1(a, a.run_variant, stats, tex, n_cu, stream, grid, launch);
     }
 }
@@ -996,7 +1001,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     if (!c->spawns) a.park_slots = 0;
     // Scenes whose hits spawn rays need the interpreter kernel (3 waves per SIMD); the others run the straight-line kernel at 3 or
     // 4 waves per SIMD. PORTRAYER_INTERP=1 (builds with -DPT_KEEP_INTERP): the interpreter on those too, for A/B runs.
-    const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH;
+    const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH || a.scene.mode == PT_MODE_KD_MESH;
     a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex) || c->four_waves_hier)) ? (c->five_waves ? 5 : 4) : 0;
     if (const char* e = getenv("PORTRAYER_WAVES")) {
         const int wv = atoi(e);
@@ -1006,8 +1011,13 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
         // The k-d semantics: mesh-free scenes with many nodes take the 4-wave straight-line kernel too (big-scene 35.7 -> 30.7 ms: the per-lane
         // k-d walk waits on its own loads, a fourth wavefront per SIMD hides more of that than the 4 spilled registers cost); with mesh
         // instances the walk needs the registers (167 at 3 waves). PORTRAYER_KD_WAVES=3|4 overrides.
-        a.four_waves = (a.scene.mode == PT_MODE_KD_NOMESH && !c->spawns && a.scene.n_nodes >= 256) ? 4 : 0;
-        if (const char* e = getenv("PORTRAYER_KD_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode == PT_MODE_KD_NOMESH && !c->spawns) ? 4 : 0;
+        // Round 4 (one walk per wavefront, pt_trace_packet_kd): mesh-free scenes with many nodes at 5 waves (big-scene 29.2 -> 28.1 ms, c10), scenes with plain
+        // Mesh instances (PT_MODE_KD_MESH: no KDMesh walker compiled in) at 4; with KDMesh trees the kernel needs its 168 registers.
+        a.four_waves = c->spawns ? 0 : ((a.scene.mode == PT_MODE_KD_NOMESH && a.scene.n_nodes >= 256) ? 5 : (a.scene.mode == PT_MODE_KD_MESH ? 4 : 0));
+        if (const char* e = getenv("PORTRAYER_KD_WAVES")) {
+            const int wv = atoi(e);
+            a.four_waves = (c->spawns || wv < 4 || a.scene.mode == PT_MODE_KD) ? 0 : ((wv >= 5 && a.scene.mode == PT_MODE_KD_NOMESH) ? 5 : 4);
+        }
     }
     // Fork / join of refracted subtrees (pt_shade.h) is built, parity-green and OFF by default: it fills the idle lanes and still loses
     // (transmission-refraction 11.4 -> 8.6 Gray/s, profiles/r03/notes.md section 4): the subtrees other lanes walk are other rays, and the
@@ -1030,6 +1040,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
         const bool flat_sem = (a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_MESH) && !tex;  // (HIER_MESH: 22.2 -> 24.2, c41)
         a.four_waves = flat_sem ? 4 : 0;
         if (const char* e = getenv("PORTRAYER_CHAIN_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode != PT_MODE_KD) ? 4 : 0;
+        else if (a.scene.mode == PT_MODE_KD_MESH && !tex) a.four_waves = 4;
     }
     size_t block_budget = a.four_waves == 5 ? 31 * 1024 : (a.four_waves ? 39 * 1024 : 52 * 1024);  // 3 x 52 KB, 4 x 39 KB or 5 x 31 KB of the CU's 160 KB
     if (const char* e = getenv("PORTRAYER_LDS_BUDGET_KB")) block_budget = (size_t)std::max(16, std::min(160, atoi(e))) * 1024;  // experiment: 80 = two blocks per CU
@@ -1052,7 +1063,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // and the k-d tree semantics are 1 % better off with batches.
     const uint64_t resident_waves = (uint64_t)grid * (PT_BLOCK / 64);
     const bool long_launch = (uint64_t)a.n_items > 2048ull * std::max<uint64_t>(resident_waves, 1);
-    const bool kd_mode = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH;
+    const bool kd_mode = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH || a.scene.mode == PT_MODE_KD_MESH;
     a.fine_queues = (c->spawns || (!long_launch && !kd_mode)) ? 16 : 0;  // 8 .. 32 queues measured alike, 64 and 4 about 1 % behind
     if (const char* e = getenv("PORTRAYER_FINE_QUEUES")) a.fine_queues = (uint32_t)std::max(0, std::min(PT_FINE_QUEUES, atoi(e)));
     a.item_stride = 1;
@@ -1343,6 +1354,7 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
     case PT_MODE_HIER_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER_NOMESH>())); break;
     case PT_MODE_KD_NOMESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_KD_NOMESH>())); break;
     case PT_MODE_HIER_MESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_HIER_MESH>())); break;
+    case PT_MODE_KD_MESH: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_KD_MESH>())); break;
     default: PT_HIP(c, cast(std::integral_constant<int, PT_MODE_FLAT>())); break;
     }
     PT_HIP(c, hipGetLastError());

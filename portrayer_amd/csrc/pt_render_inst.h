@@ -17,3 +17,4 @@ PT_DECLARE_MODE_LAUNCHER(5);  // PT_MODE_HIER
 PT_DECLARE_MODE_LAUNCHER(6);  // PT_MODE_HIER_NOMESH
 PT_DECLARE_MODE_LAUNCHER(7);  // PT_MODE_KD_NOMESH
 PT_DECLARE_MODE_LAUNCHER(8);  // PT_MODE_HIER_MESH
+PT_DECLARE_MODE_LAUNCHER(9);  // PT_MODE_KD_MESH

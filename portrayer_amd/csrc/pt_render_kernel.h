@@ -340,7 +340,7 @@ static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_
     case PT_RUN_INTERP: return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 0>>(lds, a, n_cu, stream, grid_out, launch);
 #ifdef PT_KEEP_INTERP
     case PT_RUN_INTERP4:
-        if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH) return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 2>>(lds, a, n_cu, stream, grid_out, launch);
+        if constexpr (MODE != PT_MODE_KD && MODE != PT_MODE_KD_NOMESH && MODE != PT_MODE_KD_MESH) return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 2>>(lds, a, n_cu, stream, grid_out, launch);
         return pt_launch_kernel<&pt_render_kernel<MODE, STATS, TEX, 0>>(lds, a, n_cu, stream, grid_out, launch);
 #endif
     case PT_RUN_CHAIN:
@@ -348,7 +348,7 @@ static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_
             if (a.four_waves == 4) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 4, true>>(lds, a, n_cu, stream, grid_out, launch);
         return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 3, true>>(lds, a, n_cu, stream, grid_out, launch);
     case PT_RUN_LINE5:  // mesh-free scenes in the flat_scene / hierarchical semantics: 96 registers, 5 waves per SIMD
-        if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>>(lds, a, n_cu, stream, grid_out, launch);
+        if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH || MODE == PT_MODE_KD_NOMESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>>(lds, a, n_cu, stream, grid_out, launch);
         [[fallthrough]];
     case PT_RUN_LINE4:  // the k-d tree semantics with mesh instances (per-lane walk through two levels of trees) have no 4-wave instantiation
         if constexpr (MODE != PT_MODE_KD) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 4>>(lds, a, n_cu, stream, grid_out, launch);

@@ -116,7 +116,7 @@ PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, 
         lane_stk.cap = a.stack_lds_cap - rows;
         pt_trace_packet_mesh<STATS, true, MODE == PT_MODE_HIER>(a.scene, ray, tracing, any, hit, lds + (size_t)lane_stk.cap * PT_BLOCK + (size_t)wave * rows * 64, rows * 64, lane_stk,
                                                                 a.overflow_flag, cnt);
-    } else if (MODE == PT_MODE_KD_NOMESH || MODE == PT_MODE_KD) {  // (pt_scene_upload refuses trees of more than PT_KD_WAVE_LEVELS levels)
+    } else if (MODE == PT_MODE_KD_NOMESH || MODE == PT_MODE_KD || MODE == PT_MODE_KD_MESH) {  // (pt_scene_upload refuses trees of more than PT_KD_WAVE_LEVELS levels)
         const PtKdLayout kl = pt_kd_layout<MODE>(a);
         const int lane_rows = kl.lane_rows, wrows = kl.wrows, srows = kl.srows, lds_levels = kl.lds_levels;
         PtStackSpill lane_stk = stk;
@@ -127,7 +127,7 @@ PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, 
         sav.hbm_levels = a.scene.kd_levels - lds_levels;
         sav.hbm = stk.gbase + (size_t)a.kd_sav_offset * stk.gstride;
         sav.hbm_stride = stk.gstride;
-        pt_trace_packet_kd<STATS, MODE == PT_MODE_KD, MODE == PT_MODE_KD>(a.scene, ray, tracing, any, hit, wbase, (wrows < srows ? wrows : srows) * 64, sav, lane_stk, a.overflow_flag, cnt);
+        pt_trace_packet_kd<STATS, MODE == PT_MODE_KD || MODE == PT_MODE_KD_MESH, MODE == PT_MODE_KD>(a.scene, ray, tracing, any, hit, wbase, (wrows < srows ? wrows : srows) * 64, sav, lane_stk, a.overflow_flag, cnt);
     }
 #else
     if (tracing) pt_trace<MODE, STATS>(a.scene, ray, any, hit, stk, cnt);
@@ -147,7 +147,7 @@ PT_HD uint32_t* pt_fork_queue(const PtRenderArgs& a, uint32_t* lds) {
         const int rows = pt_wave_rows(a);
         return lds + (size_t)(a.stack_lds_cap - rows) * PT_BLOCK + (size_t)wave * rows * 64;
     }
-    if (MODE == PT_MODE_KD || MODE == PT_MODE_KD_NOMESH) { const PtKdLayout kl = pt_kd_layout<MODE>(a); return lds + (size_t)kl.lane_rows * PT_BLOCK + (size_t)wave * kl.wrows * 64; }  // the first row of the wavefront's region: its stack, free between walks
+    if (MODE == PT_MODE_KD || MODE == PT_MODE_KD_NOMESH || MODE == PT_MODE_KD_MESH) { const PtKdLayout kl = pt_kd_layout<MODE>(a); return lds + (size_t)kl.lane_rows * PT_BLOCK + (size_t)wave * kl.wrows * 64; }  // the first row of the wavefront's region: its stack, free between walks
     return lds + (size_t)wave * a.stack_lds_cap * 64;
 }
 

@@ -18,7 +18,7 @@
 
 #include "pt_math.h"
 
-enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2, PT_MODE_FLAT_NOMESH = 3, PT_MODE_FLAT_KDMESH = 4, PT_MODE_HIER = 5, PT_MODE_HIER_NOMESH = 6, PT_MODE_KD_NOMESH = 7, PT_MODE_HIER_MESH = 8 };  // 8: HIER for scenes with Mesh instances but no KDMesh trees (5 has both compiled in)  // 7: KD for scenes without mesh instances;  // 6: HIER for scenes without mesh instances  // 3: FLAT without mesh instances; 4: FLAT with KDMesh trees (1 has Mesh only)
+enum { PT_MODE_FLAT = 1, PT_MODE_KD = 2, PT_MODE_FLAT_NOMESH = 3, PT_MODE_FLAT_KDMESH = 4, PT_MODE_HIER = 5, PT_MODE_HIER_NOMESH = 6, PT_MODE_KD_NOMESH = 7, PT_MODE_HIER_MESH = 8, PT_MODE_KD_MESH = 9 };  // 9: KD for scenes with Mesh instances but no KDMesh trees (2 has both compiled in)  // 8: HIER for scenes with Mesh instances but no KDMesh trees (5 has both compiled in)  // 7: KD for scenes without mesh instances;  // 6: HIER for scenes without mesh instances  // 3: FLAT without mesh instances; 4: FLAT with KDMesh trees (1 has Mesh only)
 
 // Two children per record so one fetch decides both sides. A child reference is one 32-bit word
 // (one traversal-stack slot): bit 31 clear = inner node index; bit 31 set = leaf with

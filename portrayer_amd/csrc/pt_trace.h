@@ -1538,6 +1538,133 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
 // and the slot now keeps `start` for the way back up; mirror-inverted for a lane that went far side first.
 // Nothing here is kept per stack ENTRY and lane (that would be 16 bytes x 64 lanes x depth of LDS per wavefront).
 // ------------------------------------------------------------------------------------------------
+// ---- Lane predicates as 64-bit MASKS in scalar registers. A compare writes its result there anyway (v_cmp ... -> an SGPR pair), mask
+// logic is scalar arithmetic, "any lane?" is a scalar compare with zero, and a select reads the mask back as its condition
+// (inverse ballot = a plain copy). Written with `bool`s and __ballot() the compiler materialises every predicate that is not itself a
+// compare as 0 / 1 in a vector register and compares that again - two vector instructions per ballot, about sixteen per tree step.
+// (The masks cover the lanes that are ACTIVE where the compare executes: use them in wave-uniform control flow only.)
+typedef unsigned long long pt_mask;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_MASK_ALL (~0ull)
+#define PT_F64_LT(a, b) __builtin_amdgcn_fcmp((double)(a), (double)(b), 4)   // ordered <
+#define PT_F64_LE(a, b) __builtin_amdgcn_fcmp((double)(a), (double)(b), 5)   // ordered <=
+#define PT_F64_GE(a, b) __builtin_amdgcn_fcmp((double)(a), (double)(b), 3)   // ordered >=
+#define PT_F32_GT(a, b) __builtin_amdgcn_fcmpf((float)(a), (float)(b), 2)    // ordered >
+#define PT_U32_EQ(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 32)
+#define PT_U32_GE(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 35)
+#define PT_U32_LE(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 37)
+#define PT_LANES(m) __builtin_amdgcn_inverse_ballot_w64(m)
+#define PT_POPC(m) __builtin_popcountll(m)
+#else
+#define PT_MASK_ALL 1ull
+#define PT_F64_LT(a, b) (((double)(a) < (double)(b)) ? 1ull : 0ull)
+#define PT_F64_LE(a, b) (((double)(a) <= (double)(b)) ? 1ull : 0ull)
+#define PT_F64_GE(a, b) (((double)(a) >= (double)(b)) ? 1ull : 0ull)
+#define PT_F32_GT(a, b) (((float)(a) > (float)(b)) ? 1ull : 0ull)
+#define PT_U32_EQ(a, b) (((unsigned)(a) == (unsigned)(b)) ? 1ull : 0ull)
+#define PT_U32_GE(a, b) (((unsigned)(a) >= (unsigned)(b)) ? 1ull : 0ull)
+#define PT_U32_LE(a, b) (((unsigned)(a) <= (unsigned)(b)) ? 1ull : 0ull)
+#define PT_LANES(m) ((m) != 0ull)
+#define PT_POPC(m) ((int)((m) & 1ull))
+#endif
+#define PT_MNOT(m) (~(m) & PT_MASK_ALL)
+// pt_in_range as a mask: start <= t && t < end (false for NaN)
+PT_HD pt_mask pt_in_range_m(double start, double end, double t) { return PT_F64_LE(start, t) & PT_F64_LT(t, end); }
+// pt_slab_seg_pk as a mask: the lanes whose segment [tmin, tmax] reaches the box
+PT_HD pt_mask pt_slab_seg_pk_m(const float* lo, const float* hi, const PtRayPk& q, float tmin, float tmax) {
+    const float ax = __builtin_fmaf(lo[0], q.a[0].x, q.a[0].y), bx = __builtin_fmaf(hi[0], q.b[0].x, q.b[0].y);
+    const float ay = __builtin_fmaf(lo[1], q.a[1].x, q.a[1].y), by = __builtin_fmaf(hi[1], q.b[1].x, q.b[1].y);
+    const float az = __builtin_fmaf(lo[2], q.a[2].x, q.a[2].y), bz = __builtin_fmaf(hi[2], q.b[2].x, q.b[2].y);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return PT_MNOT(PT_F32_GT(tn, tf));
+}
+PT_HD pt_mask pt_div_exp_ok_m(double x) {
+    union { double d; uint32_t u[2]; } c; c.d = x;
+    return PT_U32_LE(((c.u[1] >> 20) & 0x7FFu) - 640u, 767u);
+}
+
+// "does any lane ...": the ballot as a 64-bit scalar compared with zero on the SCALAR unit. Written as `if (__ballot(x))` the compiler
+// materialises the predicate as 0 / 1 in a vector register and compares that again (two vector instructions per wave-uniform branch).
+PT_HD bool pt_any(bool b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long m = __ballot(b);
+    asm volatile("" : "+s"(m));
+    return m != 0ull;
+#else
+    return b;
+#endif
+}
+// A wave-uniform pointer pinned to a scalar register pair (see pt_args_again: what is read through the re-read argument block would
+// otherwise be fetched again - one more dependent scalar load - in front of every use inside a loop).
+PT_HD const void* pt_pin_ptr(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long a = (unsigned long long)pt_uniform_ptr(p);
+    asm volatile("" : "+s"(a));
+    return (const void*)a;
+#else
+    return p;
+#endif
+}
+// 8 dwords at base + byte offset (32 bits): one scalar load, no 64-bit address arithmetic
+PT_HD pt_u32x8 pt_sload8_off(const void* base, uint32_t byte_off) {
+    pt_u32x8 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(byte_off) : "memory");
+#else
+    v = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(base) + byte_off);
+#endif
+    return v;
+}
+
+PT_HD pt_u32x16 pt_sload16_off(const void* base, uint32_t byte_off) {
+    pt_u32x16 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(byte_off) : "memory");
+#else
+    v = *reinterpret_cast<const pt_u32x16*>(static_cast<const char*>(base) + byte_off);
+#endif
+    return v;
+}
+
+// ---- f64 division by a denominator that is divided by again and again (a ray's direction component: every straddled split of a
+// k-d walk computes (plane - o) / d, node.rs:90-109).
+// The compiler expands an IEEE f64 division into: v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 fma), q0 = n y,
+// r = fma(-d, q0, n), q1 = v_div_fmas(r, y, q0), v_div_fixup. For operands in the normal range v_div_scale returns its operand
+// unchanged (and clears VCC, so v_div_fmas is a plain fma) and v_div_fixup returns q1 unchanged: the quotient IS
+// fma(fma(-d, n y, n), y, n y) with y = the twice-refined reciprocal of d - a function of d alone. pt_rcp_refined() computes that y
+// with the very instructions of the expansion, once per ray and axis; pt_div_fast() finishes a division in three instructions, bit
+// for bit the hardware sequence's result (not by an error analysis: by being the same operations on the same operands).
+// "Normal range" (V_DIV_SCALE_F64 / V_DIV_FIXUP_F64 in the CDNA ISA guide): both operands finite and non-zero, d and 1 / d normal,
+// exponent(n) - exponent(d) in (-1022, 768), exponent(n) > 53. pt_div_exp_ok() is a sufficient test: the biased exponent in
+// [640, 1407], i.e. 2^-383 <= |x| < 2^385; anything else - zeros, denormals, infinities, NaNs included - takes the real division.
+// Checked against `/` on the device over the whole window and its edges (tests/test_gpu_device_parity.py).
+PT_HD double pt_rcp_refined(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double e0 = __builtin_fma(-d, y0, 1.0);
+    const double y1 = __builtin_fma(y0, e0, y0);
+    const double e1 = __builtin_fma(-d, y1, 1.0);
+    return __builtin_fma(y1, e1, y1);
+#else
+    return 1.0 / d;
+#endif
+}
+PT_HD bool pt_div_exp_ok(double x) {
+    union { double d; uint32_t u[2]; } c; c.d = x;
+    return (((c.u[1] >> 20) & 0x7FFu) - 640u) <= 767u;
+}
+PT_HD double pt_div_fast(double n, double d, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double q0 = n * y;
+    const double r = __builtin_fma(-d, q0, n);
+    return __builtin_fma(r, y, q0);
+#else
+    (void)y;
+    return n / d;
+#endif
+}
+
 struct PtKdSav {
     uint32_t* lds;        // the wavefront's rows for saved bounds: slot j, half h of lane l at lds[(2 j + h) * 64 + l]
     int hbm_levels;       // levels [0, hbm_levels) live in HBM, level k >= hbm_levels in LDS slot k - hbm_levels
@@ -1630,6 +1757,25 @@ PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_
     }
 }
 
+// One split of the k-d walk for the lanes in `mine` (node.rs:112-186): which side the ends of the lane's classification segment are on
+// (s, e: Front), who crosses the plane, where (plane_t = (plane - o) / d, node.rs:90-109) and who straddles it inside the range.
+PT_HD void pt_kd_split_eval(double o, double d, double y, pt_mask d_ok, double plane, double t_min, double t_max, double start, double end, pt_mask mine,
+                            pt_mask* s_out, pt_mask* e_out, pt_mask* cross_out, pt_mask* strad_out, double* plane_t_out) {
+    const pt_mask s = PT_F64_GE((o + d * t_min) - plane, 0.0);  // infinite_plane.rs:27-35: Front
+    const pt_mask e = PT_F64_GE((o + d * t_max) - plane, 0.0);
+    const pt_mask cross = mine & (s ^ e);
+    double plane_t = 0.0;
+    pt_mask strad = 0ull;
+    if (cross) {
+        const double n = plane - o;
+        const pt_mask fast = d_ok & pt_div_exp_ok_m(n);
+        if (cross & PT_MNOT(fast)) plane_t = n / d;   // some crossing lane's operands are outside the short division's window
+        else plane_t = pt_div_fast(n, d, y);
+        strad = cross & pt_in_range_m(start, end, plane_t);
+    }
+    *s_out = s; *e_out = e; *cross_out = cross; *strad_out = strad; *plane_t_out = plane_t;
+}
+
 // wstack: the wavefront's own stack (linear, `wwords` words); sav: the lanes' saved bounds per level; lane_stk: the lanes' own stacks
 // (KDMESH only: KDMesh instances keep the reference's triangle k-d tree, which every lane walks by itself, pt_kdmesh_hit).
 template <bool STATS, bool MESH, bool KDMESH, class LaneStack>
@@ -1639,129 +1785,138 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
     // caller's ray then lives in scratch memory and is indexed there at every split)
     const PtRay ray = ray_in;
     if (has_ray) { best.t = INFINITY; best.node = PT_NO_HIT; best.sub = 0; }
-    const unsigned long long self = 1ull << PT_LANE_ID();
-    bool alive = has_ray;             // the lane still wants candidates (a shadow ray stops at its first hit)
+    // lane predicates are masks in scalar registers (see PT_LANES)
+    pt_mask alive = PT_BALLOT(has_ray);   // the lanes that still want candidates (a shadow ray stops at its first hit)
+    pt_mask in = alive;                   // the lanes taking part in the subtree of `cur`
+    const pt_mask any_m = PT_BALLOT(any);
     double start = PT_EPSILON, end = INFINITY;  // ray.rs:140; the lane's range at the current node
-    unsigned long long codes = 0;     // two bits per level of the current path (see above)
+    uint32_t codes_lo = 0, codes_hi = 0;        // two bits per level of the current path (see above): levels 0-15 / 16-31
     const PtRayPk q = pt_raypk(ray);
     const double extent = sc.kd_extent;
-    uint32_t cur = 0;                 // wave-uniform: node, its level, words on the stack, the lanes taking part in `cur`
+    // per axis: the refined reciprocal of the direction component and whether the short division may be used with it (pt_div_fast)
+    const double yx = pt_rcp_refined(ray.d.x), yy = pt_rcp_refined(ray.d.y), yz = pt_rcp_refined(ray.d.z);
+    const pt_mask okx = pt_div_exp_ok_m(ray.d.x), oky = pt_div_exp_ok_m(ray.d.y), okz = pt_div_exp_ok_m(ray.d.z);
+    const void* const kd_base = pt_pin_ptr(sc.kd);
+    const void* const ref_base = pt_pin_ptr(sc.kd_ref);
+    const uint32_t cull = (sc.kd_box != nullptr ? 1u : 0u) | (sc.node_box != nullptr ? 2u : 0u);  // (PORTRAYER_KD_NO_CULL clears both)
+    uint32_t cur = 0;                 // wave-uniform: node, its level, words on the stack
     int lev = 0, sp = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     // (pinned to scalar registers from the start: the constant 0 otherwise reaches the loop's phi as a copy of some VECTOR register that
     // also holds a 0, and the compiler's SGPR-copy fixing then moves the whole chain - and the scalar load's offset - to the vector side)
     asm volatile("" : "+s"(cur), "+s"(lev), "+s"(sp));
 #endif
-    unsigned long long in = PT_BALLOT(alive);
-    // ONE way out of the walk (the test at the bottom): an early `return` from inside these loops - with the lanes' divergent code of the
-    // failure path behind it - makes the compiler's unified loop exit a join of divergent branches, and every wave-uniform value that
-    // passes through it (the node index, the stack pointer, the lane masks) is then taken for divergent: no scalar loads, no SALU block.
+    // ONE way out of the walk (the test at the very end of the body): an early `return` from inside these loops - with the lanes' divergent
+    // code of the failure path behind it - makes the compiler's unified loop exit a join of divergent branches, and every wave-uniform value
+    // that passes through it (the node index, the stack pointer, the lane masks) is then taken for divergent: no scalar loads, no SALU block.
+    // For the same reason the lanes' own updates below are selects, not branches.
     bool failed = false;   // wave-uniform: the wavefront's stack overflowed, or the watchdog below tripped
     uint32_t steps = 0;    // wave-uniform: nodes visited by this walk. A walk visits a node at most once; one that goes on beyond any tree this
                            // library accepts is a defect (or a corrupted stack) and fails the render (PT_ERR_TRAVERSAL) instead of hanging the GPU
     for (;;) {
         steps++;
         failed = failed || steps > PT_KD_WALK_STEPS_MAX;
-#ifdef PT_KD_DEBUG
-        if (STATS && steps > PT_KD_WALK_STEPS_MAX && PT_LANE_ID() == 0u) { cnt->diag[0] = cur; cnt->diag[1] = (unsigned long long)lev; cnt->diag[2] = (unsigned long long)sp; cnt->diag[3] = in; cnt->diag[4] = (unsigned long long)wwords; cnt->diag[5] = (unsigned long long)sav.hbm_levels; }
-#endif
         bool descend = false;  // wave-uniform: go on with `cur` (a child) instead of taking the next pending subtree
         // the lanes this node can still give something: taking part, and no hit yet in front of everything below (every hit
         // below has t >= start, and ranges of different leaves never share a t)
-        bool mine = !failed && alive && (in & self) != 0ull && !(best.t < start);
-        if (PT_BALLOT(mine)) {
-            const pt_u32x16 v = pt_sload_node(sc.kd, cur);
+        pt_mask mine = failed ? 0ull : (alive & in & PT_MNOT(PT_F64_LT(best.t, start)));
+        if (mine) {
+            const pt_u32x16 v = pt_sload16_off(kd_base, cur << 6);
             PT_WAVE_COUNT(4);
             // the lane's segment [start, end), rounded outward, against the conservative f32 bounds of everything below this node:
             // a subtree the segment does not reach reports no hit, which is all the reference would find out by walking it
             float seg0 = (float)start, seg1 = (float)end;
             seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
-            if (sc.kd_box) {
+            if (cull & 1u) {
                 const float lo[3] = {pt_f32_of(v[8]), pt_f32_of(v[9]), pt_f32_of(v[10])}, hi[3] = {pt_f32_of(v[11]), pt_f32_of(v[12]), pt_f32_of(v[13])};
-                const bool reach = pt_slab_seg_pk(lo, hi, q, seg0, seg1);
-                if (STATS && mine && !reach) cnt->kd_culled++;
-                mine = mine && reach;
+                const pt_mask reach = pt_slab_seg_pk_m(lo, hi, q, seg0, seg1);
+                if (STATS && PT_LANES(mine & PT_MNOT(reach))) cnt->kd_culled++;
+                mine &= reach;
             }
             const int axis = (int)v[2];
             if (axis >= 0) {
                 // ---- a split (node.rs:112-202), for the lanes in `mine`
-                if (STATS && mine) cnt->n_inner++;
+                if (STATS && PT_LANES(mine)) cnt->n_inner++;
                 const double plane = pt_f64_of(v[0], v[1]);
                 double t_max = start + extent;                                   // node.rs:118
-                if (!pt_in_range(start, end, t_max)) t_max = end - PT_EPSILON;   // node.rs:121
+                t_max = PT_LANES(pt_in_range_m(start, end, t_max)) ? t_max : end - PT_EPSILON;   // node.rs:121
                 const double t_min = start + PT_EPSILON;                         // node.rs:124
-                const double o = axis == 0 ? ray.o.x : (axis == 1 ? ray.o.y : ray.o.z), d = axis == 0 ? ray.d.x : (axis == 1 ? ray.d.y : ray.d.z);
-                const bool s = ((o + d * t_min) - plane) >= 0.0;                 // infinite_plane.rs:27-35
-                const bool e = ((o + d * t_max) - plane) >= 0.0;
-                const bool same = s == e;
-                double plane_t = 0.0;
-                bool strad = false;
-                if (PT_BALLOT(mine && !same)) {
-                    plane_t = (plane - o) / d;                                   // node.rs:90-109
-                    strad = mine && !same && pt_in_range(start, end, plane_t);
-                    if (STATS && mine && !same && !strad) cnt->kd_plane_miss++;  // node.rs:146-147 / :177-178: the reference panics here; a miss for this subtree
-                }
-                const bool go_f = mine && (same ? s : strad), go_b = mine && (same ? !s : strad);
-                const unsigned long long m_f = PT_BALLOT(go_f), m_b = PT_BALLOT(go_b);
+                // (the same arithmetic compiled once per axis, behind a scalar branch: picking o, d and the reciprocal by a run-time axis
+                // costs twelve selects per split)
+                pt_mask s, e, cross, strad;
+                double plane_t;
+#ifndef PT_KD_AXIS_SELECT
+                if (axis == 0) pt_kd_split_eval(ray.o.x, ray.d.x, yx, okx, plane, t_min, t_max, start, end, mine, &s, &e, &cross, &strad, &plane_t);
+                else if (axis == 1) pt_kd_split_eval(ray.o.y, ray.d.y, yy, oky, plane, t_min, t_max, start, end, mine, &s, &e, &cross, &strad, &plane_t);
+                else pt_kd_split_eval(ray.o.z, ray.d.z, yz, okz, plane, t_min, t_max, start, end, mine, &s, &e, &cross, &strad, &plane_t);
+#else
+                pt_kd_split_eval(axis == 0 ? ray.o.x : (axis == 1 ? ray.o.y : ray.o.z), axis == 0 ? ray.d.x : (axis == 1 ? ray.d.y : ray.d.z), axis == 0 ? yx : (axis == 1 ? yy : yz),
+                                 axis == 0 ? okx : (axis == 1 ? oky : okz), plane, t_min, t_max, start, end, mine, &s, &e, &cross, &strad, &plane_t);
+#endif
+                if (STATS && PT_LANES(cross & PT_MNOT(strad))) cnt->kd_plane_miss++;  // node.rs:146-147 / :177-178: the reference panics here; a miss for this subtree
+                const pt_mask same = mine & PT_MNOT(s ^ e);
+                const pt_mask go_f = (same & s) | strad, go_b = (same & PT_MNOT(s)) | strad;
                 // the child most lanes call near goes first (a lane's near side is the side of its range start)
-                const int n_f = __builtin_popcountll(PT_BALLOT((go_f || go_b) && s)), n_b = __builtin_popcountll(PT_BALLOT((go_f || go_b) && !s));
-                const bool front_first = n_f >= n_b;
+                const bool front_first = PT_POPC((go_f | go_b) & s) >= PT_POPC((go_f | go_b) & PT_MNOT(s));
                 const uint32_t c_first = front_first ? v[3] : v[4], c_second = front_first ? v[4] : v[3];
-                const unsigned long long m_first = front_first ? m_f : m_b, m_second = front_first ? m_b : m_f;
-                // (the wave-uniform bookkeeping in straight-line code, before the lanes' own: a uniform value that changed inside the
-                // lanes' branches below would meet them at one join and be taken for divergent as well)
-                const bool push = m_second != 0ull;
-                const bool room = sp + 2 <= wwords;
-                if (room) { wstack[sp] = c_second; wstack[sp + 1] = (uint32_t)lev; }  // (a free slot when nothing is pushed)
+                const pt_mask in_first = front_first ? go_f : go_b, in_second = front_first ? go_b : go_f;
+                const bool push = in_second != 0ull;
+                const bool room = sp < wwords;
+                if (room) wstack[sp] = (c_second << 5) | (uint32_t)lev;  // (a free slot when nothing is pushed) one word: the child and the split's level
                 failed = failed || (push && !room);
-                descend = (m_f | m_b) != 0ull && !failed;
-                sp += (push && descend) ? 2 : 0;
-                uint32_t code = 0;
-                if (push && descend) {
-                    const bool in_first = front_first ? go_f : go_b, in_second = front_first ? go_b : go_f;
-                    if (in_first && in_second) {   // straddling: one bound becomes plane_t, the other side's comes from the slot later
-                        if (s == front_first) { pt_kd_sav_store(sav, lev, end); end = plane_t; code = 2u; }
-                        else { pt_kd_sav_store(sav, lev, start); start = plane_t; code = 3u; }
-                    } else if (in_second) {
-                        code = 1u;
-                    }
-                }
+                descend = (go_f | go_b) != 0ull && !failed;
+                sp += (push && descend) ? 1 : 0;
+                // the lanes' own bookkeeping, without branches: both children (straddling) - one bound becomes plane_t and goes to the
+                // slot, code 2 (the slot holds the end) / 3 (the start); the second child only - code 1; else 0. Lanes whose slot is not
+                // read later may write it too.
+                const pt_mask near_first = front_first ? s : PT_MNOT(s);
+                const pt_mask both = (push && descend) ? strad : 0ull;
+                if (both) pt_kd_sav_store(sav, lev, PT_LANES(near_first) ? end : start);
+                uint32_t code = PT_LANES((push && descend) ? in_second : 0ull) ? 1u : 0u;
+                code = PT_LANES(both & near_first) ? 2u : code;
+                code = PT_LANES(both & PT_MNOT(near_first)) ? 3u : code;
+                end = PT_LANES(both & near_first) ? plane_t : end;
+                start = PT_LANES(both & PT_MNOT(near_first)) ? plane_t : start;
                 if (descend) {
-                    codes = (codes & ~(3ull << (2 * lev))) | ((unsigned long long)code << (2 * lev));
-                    in = m_first; cur = c_first; lev++;
+                    const int sh = 2 * (lev & 15);
+                    if (lev < 16) codes_lo = (codes_lo & ~(3u << sh)) | (code << sh);
+                    else codes_hi = (codes_hi & ~(3u << sh)) | (code << sh);
+                    in = in_first; cur = c_first; lev++;
                 }
-            } else if (PT_BALLOT(mine)) {
+            } else if (mine) {
                 // ---- a leaf: ray.rs:87-99 fold over the leaf's nodes in the reference's order with a strictly shrinking end
-                if (STATS && mine) cnt->n_leaf++;
+                if (STATS && PT_LANES(mine)) cnt->n_leaf++;
                 PT_WAVE_COUNT(5);
                 const uint32_t first = v[5], count = v[6];
                 PtHit lb; lb.t = end; lb.node = PT_NO_HIT; lb.sub = 0;
-                bool found = false;
-                bool want = mine;  // a shadow ray is done with its first hit
+                pt_mask found = 0ull;
+                pt_mask want = mine;  // a shadow ray is done with its first hit
+                const void* const info_base = pt_pin_ptr(sc.info);
+                const void* const inv_base = pt_pin_ptr(sc.inv);
                 for (uint32_t i = 0; i < count; i++) {
                     // the reference and its cull box in one scalar fetch: {flattened node, 0, the node's padded world box as 6 f32 rounded outward}
-                    const pt_u32x8 ref = pt_sload8(sc.kd_ref + 8 * (size_t)(first + i));
+                    const pt_u32x8 ref = pt_sload8_off(ref_base, (first + i) << 5);
+                    PT_WAVE_COUNT(6);  // -DPT_DIAG: leaf references looked at, per wavefront (per lane: n_bbox)
                     const uint32_t item = ref[0];
-                    bool test = want;
-                    if (sc.node_box) {  // a node whose box the lane's segment does not reach cannot report a hit in it
+                    pt_mask test = want;
+                    if (cull & 2u) {  // a node whose box the lane's segment does not reach cannot report a hit in it
                         const float lo[3] = {pt_f32_of(ref[2]), pt_f32_of(ref[3]), pt_f32_of(ref[4])}, hi[3] = {pt_f32_of(ref[5]), pt_f32_of(ref[6]), pt_f32_of(ref[7])};
-                        if (STATS && want) cnt->n_bbox++;
-                        test = want && pt_slab_seg_pk(lo, hi, q, seg0, seg1);
+                        if (STATS && PT_LANES(want)) cnt->n_bbox++;
+                        test &= pt_slab_seg_pk_m(lo, hi, q, seg0, seg1);
                     }
-                    if (!PT_BALLOT(test)) continue;
+                    if (!test) continue;
+                    PT_WAVE_COUNT(7);  // -DPT_DIAG: exact tests, per wavefront (per lane: n_analytic)
                     // the node's record in one round trip through the scalar cache: {type, data, flags, material} and rows 0..2 of its inverse
                     pt_u32x4 info;
                     pt_u32x16 ma;
                     pt_u32x8 mb;
-                    const void* info_ptr = sc.info + 4 * (size_t)item;
-                    const void* rec = sc.inv + 12 * (size_t)item;
 #if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&s"(info), "=&s"(ma), "=&s"(mb) : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(rec)) : "memory");
+                    asm volatile("s_load_dwordx4 %0, %3, %5\n\ts_load_dwordx16 %1, %4, %6\n\ts_load_dwordx8 %2, %4, %7\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&s"(info), "=&s"(ma), "=&s"(mb) : "s"(info_base), "s"(inv_base), "s"(item << 4), "s"(item * 96u), "s"(item * 96u + 64u) : "memory");
 #else
-                    info = *static_cast<const pt_u32x4*>(info_ptr);
-                    ma = *static_cast<const pt_u32x16*>(rec);
-                    mb = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(rec) + 64);
+                    info = *reinterpret_cast<const pt_u32x4*>(static_cast<const char*>(info_base) + ((size_t)item << 4));
+                    ma = *reinterpret_cast<const pt_u32x16*>(static_cast<const char*>(inv_base) + (size_t)item * 96u);
+                    mb = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(inv_base) + (size_t)item * 96u + 64u);
 #endif
                     const uint32_t type = info[0], data = info[1];
                     double mm[12];
@@ -1770,26 +1925,27 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
 #pragma unroll
                     for (int k = 0; k < 4; k++) mm[8 + k] = pt_f64_of(mb[2 * k], mb[2 * k + 1]);
                     const PtRay local = pt_ray_to_local(mm, ray);  // flat_scene.rs:74
-                    if (STATS && test) cnt->n_analytic++;
+                    const bool test_l = PT_LANES(test);
+                    if (STATS && test_l) cnt->n_analytic++;
                     bool hit = false;
                     if (MESH && (type == PT_MESH || type == PT_KDMESH)) {
                         const PtMeshInfo* mi = sc.meshes + data;
                         if (KDMESH && type == PT_KDMESH && (int32_t)PT_UNIFORM_U32((uint32_t)mi->kd_root) >= 0) {  // the reference's own triangle tree (quirk Q3), per lane
-                            if (test) {
+                            if (test_l) {
                                 double t; uint32_t tri = 0;
                                 if (pt_kdmesh_hit<STATS>(sc, *mi, local, start, pt_cand_end(lb, item, 0), lane_stk, 0, &t, &tri, cnt)) { lb.t = t; lb.node = item; lb.sub = tri; hit = true; }
                             }
                         } else {  // mesh.rs:146-155: box test, then the triangles (also a KDMesh without a tree of its own: PORTRAYER_KDMESH_AS_MESH)
                             const uint32_t root = PT_UNIFORM_U32(mi->blas_root);
-                            if (STATS && test) cnt->n_bbox++;
+                            if (STATS && test_l) cnt->n_bbox++;
                             if (root == PT_REF_EMPTY) continue;
                             double bi[12];
                             pt_sload_mat12(mi->bbox_inv, bi);
-                            const bool inside = test && pt_bbox_test_hit(bi, local, start, pt_cand_end(lb, item, 0));
-                            if (!PT_BALLOT(inside)) continue;
-                            if (!pt_packet_mesh_below_kd<STATS>(sc, item, root, local, inside, start, any, lb, hit, wstack + sp, wwords - sp, cnt)) failed = true;
+                            const bool inside = test_l && pt_bbox_test_hit(bi, local, start, pt_cand_end(lb, item, 0));
+                            if (!pt_any(inside)) continue;
+                            if (!pt_packet_mesh_below_kd<STATS>(sc, item, root, local, inside, start, PT_LANES(any_m), lb, hit, wstack + sp, wwords - sp, cnt)) failed = true;
                         }
-                    } else if (test) {
+                    } else if (test_l) {
                         double t; uint32_t part = 0;
                         if (type == PT_TRIANGLE) {  // stand-alone triangle, stored after the mesh triangles
                             double beta, gamma;
@@ -1801,46 +1957,62 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                         }
                         if (hit) { lb.t = t; lb.node = item; lb.sub = part; }
                     }
-                    if (hit) {
-                        found = true;
-                        if (any) want = false;
-                        // the segment has shrunk: later references of this leaf are culled against the new end
-                        seg1 = (float)lb.t; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
-                    }
+                    const pt_mask hit_m = PT_BALLOT(hit);
+                    found |= hit_m;
+                    want &= PT_MNOT(hit_m & any_m);
+                    // the segment has shrunk: later references of this leaf are culled against the new end
+                    if (hit_m) { const float s1 = (float)lb.t; seg1 = PT_LANES(hit_m) ? s1 + fabsf(s1) * 2.4e-7f : seg1; }
                 }
                 if (found) {  // (start <= lb.t < best.t by the admission test above)
-                    best = lb;
-                    if (any) alive = false;
+                    const bool f = PT_LANES(found);
+                    best.t = f ? lb.t : best.t; best.node = f ? lb.node : best.node; best.sub = f ? lb.sub : best.sub;
+                    alive &= PT_MNOT(found & any_m);
                 }
             }
         }
         if (descend) continue;
-        // ---- the next pending subtree: the second child of the split at level L
-        if (failed || !PT_BALLOT(alive) || sp == 0) break;
-        sp -= 2;
-        cur = PT_UNIFORM_U32(wstack[sp]);
-        const int L = (int)PT_UNIFORM_U32(wstack[sp + 1]);
+        // ---- the next pending subtree: the second child of the split at level L. (The way out of the walk is tested at the very end of
+        // the body and everything before it runs either way - reading slot 0 of an empty stack is harmless -: on a path that leaves the loop
+        // early the node index would be undefined, the compiler gives undefined values VECTOR registers, and its SGPR-copy fixing then moves
+        // the whole chain of the node index to the vector side, where the scalar load cannot take it.)
+        const bool done = failed || alive == 0ull || sp == 0;
+        sp -= done ? 0 : 1;
+        const uint32_t entry = PT_UNIFORM_U32(wstack[sp]);
+        cur = entry >> 5;
+        const int L = (int)(entry & 31u);
         for (int k = lev - 1; k > L; k--) {  // the finished levels below it: put the replaced bounds back
-            const uint32_t c = (uint32_t)(codes >> (2 * k)) & 3u;
-            if (PT_BALLOT(c >= 2u)) {
-                if (c >= 2u) {
-                    const double sv = pt_kd_sav_load(sav, k);
-                    if (c == 2u) end = sv; else start = sv;
-                }
+            const uint32_t c = ((k < 16 ? codes_lo : codes_hi) >> (2 * (k & 15))) & 3u;
+            const pt_mask c2m = PT_U32_EQ(c, 2u), c3m = PT_U32_EQ(c, 3u);
+            if (c2m | c3m) {
+                const double sv = pt_kd_sav_load(sav, k);  // (lanes whose slot holds nothing read it too: not used)
+                end = PT_LANES(c2m) ? sv : end;
+                start = PT_LANES(c3m) ? sv : start;
             }
         }
         {
-            const uint32_t c = (uint32_t)(codes >> (2 * L)) & 3u;
-            uint32_t c2 = 0u;
-            if (PT_BALLOT(c >= 2u)) {
-                if (c == 2u) { const double pt = end; end = pt_kd_sav_load(sav, L); pt_kd_sav_store(sav, L, start); start = pt; c2 = 3u; }        // had [start, plane_t): now [plane_t, end)
-                else if (c == 3u) { const double pt = start; start = pt_kd_sav_load(sav, L); pt_kd_sav_store(sav, L, end); end = pt; c2 = 2u; }  // had [plane_t, end): now [start, plane_t)
+            const int sh = 2 * (L & 15);
+            const uint32_t c = ((L < 16 ? codes_lo : codes_hi) >> sh) & 3u;
+            const pt_mask c2m = PT_U32_EQ(c, 2u), c3m = PT_U32_EQ(c, 3u);
+            if (c2m | c3m) {
+                // had [start, plane_t) (c == 2, the slot holds the end): now [plane_t, end), the slot keeps the start for the way back up;
+                // had [plane_t, end) (c == 3, the slot holds the start): now [start, plane_t), the slot keeps the end
+                const double sv = pt_kd_sav_load(sav, L);
+                pt_kd_sav_store(sav, L, PT_LANES(c2m) ? start : end);
+                const double ns = PT_LANES(c2m) ? end : (PT_LANES(c3m) ? sv : start);
+                const double ne = PT_LANES(c2m) ? sv : (PT_LANES(c3m) ? start : end);
+                start = ns; end = ne;
             }
-            in = PT_BALLOT(c != 0u);
-            codes = (codes & ~(3ull << (2 * L))) | ((unsigned long long)c2 << (2 * L));
+            in = PT_MNOT(PT_U32_EQ(c, 0u));
+            const uint32_t c2 = PT_LANES(c2m) ? 3u : (PT_LANES(c3m) ? 2u : 0u);
+            if (L < 16) codes_lo = (codes_lo & ~(3u << sh)) | (c2 << sh);
+            else codes_hi = (codes_hi & ~(3u << sh)) | (c2 << sh);
         }
         lev = L + 1;
+        if (done) break;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : : "s"(cur), "s"(lev), "s"(sp));  // (live, and in scalar registers, on the way out: see above)
+#endif
     if (failed) {  // never expected (pt_scene_upload sizes the stack); recorded unconditionally so that a render whose results would be wrong cannot return PT_OK
 #if defined(__HIP_DEVICE_COMPILE__)
         if (overflow) atomicOr(overflow, steps > PT_KD_WALK_STEPS_MAX ? 4u : 1u);  // 4: the watchdog
@@ -1853,7 +2025,7 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
 // Traversal of one ray in the semantics of `MODE` (PT_MODE_*).
 template <int MODE, bool STATS, class Stack>
 PT_HD void pt_trace(const PtSceneView& sc, const PtRay& ray, bool any, PtHit& hit, const Stack& stk, PtCounters* cnt) {
-    if (MODE == PT_MODE_KD) pt_trace_kd<STATS, true>(sc, ray, any, hit, stk, cnt);
+    if (MODE == PT_MODE_KD || MODE == PT_MODE_KD_MESH) pt_trace_kd<STATS, true>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_KD_NOMESH) pt_trace_kd<STATS, false>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_NOMESH) pt_trace_flat_simple<STATS>(sc, ray, any, hit, stk, cnt);
     else if (MODE == PT_MODE_FLAT_KDMESH) pt_trace_flat<STATS, true, true>(sc, ray, any, hit, stk, cnt);

@@ -31,6 +31,35 @@ def test_device_arithmetic_is_ieee(ctx):
     assert np.array_equal(ctx.math(3, x, y), x * y + x)
 
 
+def test_short_division_of_the_kd_walk_is_the_hardware_division(ctx):
+    """Every straddled split of the k-d walk divides by the same direction component: pt_div_fast() finishes a division in three
+    instructions from a reciprocal refined once per ray (pt_trace.h). It must be `/` bit for bit wherever its exponent test admits the
+    operands (biased exponents in [640, 1407]); everything else - zeros, denormals, infinities, NaNs, huge and tiny values - must be
+    refused (NaN marker here; the walk then takes the real division). Random mantissas over the whole window, its edges, exact
+    quotients, powers of two, operands one ulp apart."""
+    rng = np.random.default_rng(9)
+    n = 400000
+    def rnd(lo, hi, k):
+        return np.ldexp(rng.uniform(0.5, 1.0, k), rng.integers(lo, hi, k).astype(np.int32)) * rng.choice([-1.0, 1.0], k)
+    a = np.concatenate([rnd(-382, 385, n), rnd(-40, 40, n), rnd(-382, -370, n // 4), rnd(373, 385, n // 4), rnd(-1070, 1024, n // 4)])
+    b = np.concatenate([rnd(-382, 385, n), rnd(-40, 40, n), rnd(373, 385, n // 4), rnd(-382, -370, n // 4), rnd(-1070, 1024, n // 4)])
+    ints = rng.integers(1, 1 << 20, n // 4).astype(np.float64)
+    a = np.concatenate([a, ints * rng.integers(1, 1 << 20, n // 4), np.ldexp(1.0, rng.integers(-300, 300, 1000)), np.nextafter(b[:1000], np.inf),
+                        np.array([0.0, -0.0, np.inf, np.nan, 5e-324, 1e-310, 1.0, 1.0, 1.0, 3.0])])
+    b = np.concatenate([b, ints, np.ldexp(1.0, rng.integers(-300, 300, 1000)) * 3.0, b[:1000],
+                        np.array([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, np.inf, np.nan, 5e-324])])
+    got = ctx.math(7, a, b)
+    def biased(x):
+        return ((x.view(np.uint64) >> np.uint64(52)) & np.uint64(0x7FF)).astype(np.int64)
+    admitted = (biased(a) >= 640) & (biased(a) <= 1407) & (biased(b) >= 640) & (biased(b) <= 1407)
+    assert np.isnan(got[~admitted]).all(), "an operand outside the window was not refused"
+    with np.errstate(all="ignore"):
+        exact = a / b
+    assert admitted.sum() > 2 * n
+    assert np.array_equal(got[admitted].view(np.uint64), exact[admitted].view(np.uint64))
+    assert np.array_equal(ctx.math(1, a[admitted], b[admitted]).view(np.uint64), exact[admitted].view(np.uint64))  # and the device's `/` is numpy's
+
+
 def libm_pow(x, y):
     """x ** y by this machine's libm (what the oracle and the reference call), NOT numpy's own vectorised pow"""
     from portrayer_amd import _hip as H
