@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="profiling: only the headline kernel (no host-buffer pass, no default-semantics pass)")
     ap.add_argument("--check", action="store_true", help="compare rank 0's assembled image with a single-GPU render")
-    ap.add_argument("--no-pipeline", action="store_true", help="--via torch, nccl: wait for each frame's gather before rendering the next")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: wait for each frame (its gather, its image) before queueing the next")
     ap.add_argument("--force-dist", action="store_true", help="testing: take the torch.distributed path even with one rank")
     ap.add_argument("--share", type=int, default=1, help="testing: render only one rank's tiles of an N-rank partition (no gather)")
     ap.add_argument("--share-rank", type=int, default=0, help="testing: which rank's tiles --share renders")
@@ -300,7 +300,28 @@ def main():
                         raise RuntimeError("pt_node_render_resident: " + lib.pt_node_last_error(node).decode())
                     return st.as_dict()
                 counts = node_step(stats=True)  # also the proof that the whole path runs before anything is timed
-                state = dict(scene=scene, renderer=renderer, node=node, cam=cam, step=node_step, counts=counts, prep=(t0, t1, t2), devices=devices)
+
+                def node_frames(k, pipelined):
+                    """k frames through pt_node_frame_begin / pt_node_frame_end: two frames open at a time (frame i + 1 renders while frame i is
+                    gathered and untiled, the host's launches hidden behind the GPUs' work) or one (every frame waited for before the next)."""
+                    q = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), s, 0, H.SAMPLE_RNG, 1, 0, 1, 0)
+                    st, kms, host_ms = H.PtStats(), [], []
+                    hm = (C.c_double * 5)()
+
+                    def end():
+                        if lib.pt_node_frame_end(node, C.byref(st)) != 0:
+                            raise RuntimeError("pt_node_frame_end: " + lib.pt_node_last_error(node).decode())
+                        lib.pt_node_last_frame_host_ms(node, C.byref(hm))
+                        kms.append(st.kernel_ms); host_ms.append([float(x) for x in hm])
+                    for i in range(k):
+                        if lib.pt_node_frame_begin(node, C.byref(cam), C.byref(q)) != 0:
+                            raise RuntimeError("pt_node_frame_begin: " + lib.pt_node_last_error(node).decode())
+                        if not pipelined or i > 0:
+                            end()
+                    if pipelined and k > 0:
+                        end()
+                    return kms, host_ms
+                state = dict(scene=scene, renderer=renderer, node=node, cam=cam, step=node_step, frames=node_frames, counts=counts, prep=(t0, t1, t2), devices=devices)
             except Exception as e:  # noqa: BLE001 - whatever went wrong, the run falls back to the torch path and says so
                 node_note = f"{type(e).__name__}: {e}"
                 os.environ.pop("PORTRAYER_DEVICES", None)
@@ -309,17 +330,19 @@ def main():
         node_note = flag[0]
         if node_note is None:
             out = None
-            for _ in range(args.warmup):
-                if rank == 0:
-                    state["step"]()
+            if rank == 0:
+                state["frames"](args.warmup, not args.no_pipeline)
             dist.barrier()
             t0 = time.perf_counter()
             kernel_ms = []
-            if rank == 0:
-                for _ in range(args.steps):
-                    kernel_ms.append(state["step"]()["kernel_ms"])  # returns when the frame is assembled on GPU 0 (every rank's stream synchronised)
+            if rank == 0:  # K frames; the last one is closed (its image assembled on GPU 0) before the clock stops
+                kernel_ms, _ = state["frames"](args.steps, not args.no_pipeline)
             dist.barrier()
             elapsed = time.perf_counter() - t0
+            if rank == 0:  # untimed: the same frames one at a time, for what the host adds to a frame that nothing overlaps
+                t1 = time.perf_counter()
+                lat_kernel, lat_host = state["frames"](max(args.steps, 3), False)
+                state["latency"] = ((time.perf_counter() - t1) * 1e3 / max(args.steps, 3), lat_kernel, lat_host)
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -573,7 +596,19 @@ def node_report(args, H, host, lib, state, world, w, h, s, example, elapsed, ker
                                    "backend": "RCCL: ncclCommInitAll + one grouped ncclGather over xGMI" if lib.pt_node_uses_rccl(node) else "device-to-device copies (ranks share a GPU: RCCL needs distinct devices)",
                                    "uses_rccl": bool(lib.pt_node_uses_rccl(node)), "ranks_in_group": ranks,
                                    "devices": [int(lib.pt_node_device(node, r)) for r in range(ranks)],
-                                   "per_frame": "one gather of %d B per rank" % per, "rank_processes": world}
+                                   "per_frame": "one gather of %d B per rank" % per, "rank_processes": world,
+                                   "frames": "pt_node_frame_begin / _end, one frame at a time (--no-pipeline)" if args.no_pipeline else
+                                             "pt_node_frame_begin / _end, two frames open: frame k + 1 renders while frame k is gathered and untiled"}
+    if state.get("latency"):
+        frame_ms, lat_kernel, lat_host = state["latency"]
+        hm = np.median(np.array(lat_host), axis=0)
+        out["config"]["collective"]["one_frame_at_a_time"] = {
+            "frame_ms": frame_ms, "slowest_rank_kernel_ms": float(np.median(lat_kernel)), "sum_of_rank_kernels_ms": float(hm[4]),
+            "host_begin_ms": float(hm[0]), "host_slowest_rank_launch_ms": float(hm[3]), "host_blocked_on_gpu_ms": float(hm[1]), "host_finish_ms": float(hm[2]),
+            "host_overhead_ms": float(hm[0] + hm[2]),
+            "frame_minus_sum_of_rank_kernels_ms": frame_ms - float(hm[4]),
+            "note": "untimed pass after the timed one, median of the frames; host_overhead_ms = what pt_node_frame_begin and the tail of pt_node_frame_end spend on the host. "
+                    "Ranks that share a GPU run their kernels side by side, so frame - sum of kernels says little there; with one GPU per rank the frame is the slowest kernel + gather + this overhead"}
     t0, t1, t2 = state["prep"]
     out["config"]["prepare_ms"] = dict(renderer.prepare_ms(), scene_script=(t1 - t0) * 1e3, renderer_total=(t2 - t1) * 1e3)
     if args.check:

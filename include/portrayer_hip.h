@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 6
+#define PT_ABI_VERSION 7
 
 /* enum Primitive, src/primitive.rs:67-81 */
 enum { PT_PRIM_SPHERE = 0, PT_PRIM_TRIANGLE = 1, PT_PRIM_MESH = 2, PT_PRIM_KDMESH = 3, PT_PRIM_PLANE = 4, PT_PRIM_CUBE = 5, PT_PRIM_CYLINDER = 6, PT_PRIM_CONE = 7 };
@@ -261,6 +261,18 @@ int pt_node_upload_background(pt_node *node, const double *background, const pt_
 int pt_node_render_resident(pt_node *node, const pt_camera *camera, const pt_render_params *params, pt_stats *stats);
 int pt_node_download_image(pt_node *node, const pt_render_params *params, uint8_t *rgb);
 int pt_node_device(const pt_node *node, int rank);
+/* (ABI 7) Frames in a pipeline. pt_node_frame_begin queues a frame - every rank's render (launched by the rank's own host thread), the ONE
+ * gather and the untile - and returns without waiting; pt_node_frame_end closes the OLDEST open frame: it returns when that frame's image is
+ * complete on rank 0, with its stats (counters summed over the ranks, kernel_ms of the slowest rank). Up to two frames may be open: their
+ * tile buffers are separate and the gather runs on streams of its own, so frame k + 1 renders while frame k is gathered and untiled, and
+ * the host's launch work disappears behind the GPUs' (render.rs:93-151 renders one frame per call: pt_node_render_resident = begin + end).
+ * The image on rank 0 is a single buffer: pt_node_download_image (and pt_node_upload_background) need every frame closed.
+ * pt_node_last_frame_host_ms: host milliseconds of the last frame's calls - [0] begin as a whole, [1] end blocked until the image was
+ * complete, [2] end after that, [3] the slowest rank's launch inside begin, [4] the ranks' kernel times added up. */
+int pt_node_frame_begin(pt_node *node, const pt_camera *camera, const pt_render_params *params);
+int pt_node_frame_end(pt_node *node, pt_stats *stats);
+int pt_node_frames_in_flight(const pt_node *node);
+int pt_node_last_frame_host_ms(const pt_node *node, double out[5]);
 
 /* Device-side helpers used by the measurement harness. */
 int pt_device_alloc(pt_context *ctx, uint64_t bytes, void **out);

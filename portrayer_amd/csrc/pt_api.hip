@@ -193,12 +193,25 @@ struct pt_context {
     bool five_waves = false;   // ... mesh-free: 5 waves per SIMD (96 registers)
     PtSceneView view;
     bool have_scene = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool pending = false;
-    bool pending_stats = false;
-    uint32_t last_mode = 0, last_variant = 0;  // pt_stats.kernel_mode / kernel_variant of the launch in flight
-    std::chrono::steady_clock::time_point t_start;
+    // Up to PT_SLOTS renders of one context may be in flight on a stream (pt_render_device ... pt_render_finish, oldest first): a frame's
+    // events and the page of pinned host memory its overflow flag and counters are copied to - asynchronously, right behind its kernels -
+    // belong to its slot, so closing a frame is an event wait and a read of host memory: no blocking copy, and the next frame may already
+    // be queued behind it (pt_node: frame k + 1 renders while frame k is gathered). The device-side buffers are shared: the stream orders them.
+    struct Slot {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the kernels (pt_stats.kernel_ms)
+        hipEvent_t copy_done = nullptr;            // behind the copy into `host`
+        unsigned char* host = nullptr;   // pinned: [0, 8) work counter + overflow flag, [256, 256 + sizeof(PtCounters)) the counters
+        bool pending = false, counted = false;
+        uint32_t mode = 0, variant = 0;  // pt_stats.kernel_mode / kernel_variant of the launch
+        std::chrono::steady_clock::time_point t_start;
+    };
+    static constexpr int PT_SLOTS = 2;
+    Slot slot[PT_SLOTS];
+    int slot_next = 0;     // the slot the next launch takes
+    int slot_oldest = 0;   // the oldest launch not yet closed (== slot_next: none, unless every slot is pending)
+    uint32_t last_mode = 0, last_variant = 0;
 };
+#define PT_SLOT_BYTES (256 + sizeof(PtCounters))
 
 static int pt_fail(pt_context* c, int code, const std::string& msg) {
     if (c) c->err = msg;
@@ -245,7 +258,12 @@ extern "C" int pt_context_create(int device, pt_context** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return PT_ERR_DEVICE; }
     c->n_cu = prop.multiProcessorCount;
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return PT_ERR_DEVICE; }
+    for (auto& sl : c->slot)
+        if (hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess || hipEventCreateWithFlags(&sl.copy_done, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void**)&sl.host, PT_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) {
+            pt_context_destroy(c);
+            return PT_ERR_DEVICE;
+        }
     memset(&c->view, 0, sizeof c->view);
     *out = c;
     return PT_OK;
@@ -257,8 +275,12 @@ extern "C" void pt_context_destroy(pt_context* c) {
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_n, &c->meshes, &c->materials, &c->lights,
                      &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->kd_ref, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank, &c->hier_rec};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
+    for (auto& sl : c->slot) {
+        if (sl.ev0) hipEventDestroy(sl.ev0);
+        if (sl.ev1) hipEventDestroy(sl.ev1);
+        if (sl.copy_done) hipEventDestroy(sl.copy_done);
+        if (sl.host) hipHostFree(sl.host);
+    }
     delete c;
 }
 
@@ -990,7 +1012,7 @@ extern "C" int pt_test_work_items(const pt_render_params* p, uint32_t* sample_co
     return PT_OK;
 }
 
-static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStream_t stream) {
+static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStream_t stream, int slot_index = -1) {
     // LDS per block = traversal stack (as much of it as leaves room for three blocks per CU) + the shaded hit's frame (+ a parked one);
     // deeper stack entries live in HBM (PtStackSpill).
     if (getenv("PORTRAYER_NO_TEX")) a.scene.mat_maps = nullptr;  // experiment: the untextured kernel on a textured scene (wrong picture, timing only)
@@ -1093,29 +1115,40 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     c->last_variant = (a.four_waves ? (uint32_t)a.four_waves : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4 || a.run_variant == PT_RUN_LINE5 || a.run_variant == PT_RUN_CHAIN) ? 0u : PT_KERNEL_INTERPRETER) | (a.run_variant == PT_RUN_CHAIN ? PT_KERNEL_CHAIN : 0u) |
                       ((a.run_variant == PT_RUN_INTERP_PARK || a.run_variant == PT_RUN_INTERP_FORK) ? PT_KERNEL_PARK : 0u) | (a.run_variant == PT_RUN_INTERP_FORK ? PT_KERNEL_FORK : 0u) | (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
     PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
-    PT_HIP(c, hipEventRecord(c->ev0, stream));
+    if (slot_index < 0) {  // the host-buffer path (pt_render): one frame at a time
+        if (c->slot[c->slot_oldest].pending) return pt_fail(c, PT_ERR_ARGUMENT, "a render is in flight: pt_render_finish first");
+        slot_index = c->slot_next;
+    }
+    pt_context::Slot& sl = c->slot[slot_index];
+    sl.mode = c->last_mode; sl.variant = c->last_variant; sl.counted = stats;
+    PT_HIP(c, hipEventRecord(sl.ev0, stream));
     if (a.n_items) {
         PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, true));
         hipLaunchKernelGGL(pt_finish_kernel, dim3((a.n_slots + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, stream, a);
         PT_HIP(c, hipGetLastError());
     }
-    PT_HIP(c, hipEventRecord(c->ev1, stream));
+    PT_HIP(c, hipEventRecord(sl.ev1, stream));
+    // the overflow flag (always) and the counters (counting build) follow the kernels into the slot's pinned page
+    PT_HIP(c, hipMemcpyAsync(sl.host, c->misc.p, stats ? PT_SLOT_BYTES : 8, hipMemcpyDeviceToHost, stream));
+    PT_HIP(c, hipEventRecord(sl.copy_done, stream));
     return PT_OK;
 }
 
-// Reads back the overflow flag (always) and, for the counting build, the counters. A launch in which any lane ran
-// out of traversal stack fails with PT_ERR_TRAVERSAL whether or not the caller asked for statistics.
-static int pt_collect_stats(pt_context* c, pt_stats* st, bool counted) {
+// Reads the overflow flag (always) and, for the counting build, the counters of a finished launch out of its slot's pinned page (the
+// caller has waited for the stream: the copy queued behind the kernels is done). A launch in which any lane ran out of traversal
+// stack fails with PT_ERR_TRAVERSAL whether or not the caller asked for statistics.
+static int pt_collect_stats(pt_context* c, pt_stats* st, int slot_index) {
+    pt_context::Slot& sl = c->slot[slot_index];
     if (st) memset(st, 0, sizeof *st);
-    unsigned int head[2] = {0, 0};  // work counter, overflow flag
-    PT_HIP(c, hipMemcpy(head, c->misc.p, sizeof head, hipMemcpyDeviceToHost));
+    unsigned int head[2];  // work counter, overflow flag
+    memcpy(head, sl.host, sizeof head);
     if (st) {
         float ms = 0.f;
-        PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        PT_HIP(c, hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
         st->kernel_ms = ms;
-        if (counted) {
+        if (sl.counted) {
             PtCounters h;
-            PT_HIP(c, hipMemcpy(&h, (char*)c->misc.p + 256, sizeof h, hipMemcpyDeviceToHost));
+            memcpy(&h, sl.host + 256, sizeof h);
             st->primary = h.primary; st->shadow = h.shadow; st->reflect = h.reflect; st->refract = h.refract;
             st->depth11_skipped = h.depth11_skipped; st->hits = h.hits; st->n_inner = h.n_inner; st->n_leaf = h.n_leaf;
             st->n_analytic = h.n_analytic; st->n_tri = h.n_tri; st->n_bbox = h.n_bbox; st->kd_plane_miss = h.kd_plane_miss;
@@ -1123,7 +1156,7 @@ static int pt_collect_stats(pt_context* c, pt_stats* st, bool counted) {
             for (int k = 0; k < 8; k++) st->diag[k] = h.diag[k];
         }
         if (head[1] && !st->stack_overflow) st->stack_overflow = 1;
-        st->kernel_mode = c->last_mode; st->kernel_variant = c->last_variant;
+        st->kernel_mode = sl.mode; st->kernel_variant = sl.variant;
     }
     if (head[1] & 2u) return pt_fail(c, PT_ERR_TRAVERSAL, "fork / join of refracted subtrees stalled (a lane waited for a colour nobody was computing): results invalid");
     if (head[1] & 4u) return pt_fail(c, PT_ERR_TRAVERSAL, "a tree walk did not end (watchdog): results invalid");
@@ -1153,11 +1186,12 @@ extern "C" int pt_render(pt_context* c, const pt_camera* cam, const double* back
     a.rgb = (uint8_t*)c->rgb.p;
     a.linear = linear ? (double*)c->linear.p : nullptr;
     bool counted = p->collect_stats != 0;
+    const int slot_index = c->slot_next;
     if ((rc = pt_render_common(c, a, counted, nullptr))) return rc;
     PT_HIP(c, hipDeviceSynchronize());
     PT_HIP(c, hipMemcpy(rgb, c->rgb.p, px * 3, hipMemcpyDeviceToHost));
     if (linear) PT_HIP(c, hipMemcpy(linear, c->linear.p, px * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    rc = pt_collect_stats(c, stats, counted);
+    rc = pt_collect_stats(c, stats, slot_index);
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
@@ -1174,21 +1208,26 @@ extern "C" int pt_render_device(pt_context* c, const pt_camera* cam, const doubl
     a.compact = compact ? 1 : 0;
     a.rgb = (uint8_t*)d_rgb;
     a.linear = nullptr;
-    c->pending_stats = p->collect_stats != 0;
-    c->t_start = std::chrono::steady_clock::now();
-    if ((rc = pt_render_common(c, a, c->pending_stats, (hipStream_t)hip_stream))) return rc;
-    c->pending = true;
+    const int slot_index = c->slot_next;
+    if (c->slot[slot_index].pending) return pt_fail(c, PT_ERR_ARGUMENT, "too many renders in flight on this context: pt_render_finish first");
+    c->slot[slot_index].t_start = std::chrono::steady_clock::now();
+    if ((rc = pt_render_common(c, a, p->collect_stats != 0, (hipStream_t)hip_stream, slot_index))) return rc;
+    c->slot[slot_index].pending = true;
+    c->slot_next = (slot_index + 1) % pt_context::PT_SLOTS;
     return PT_OK;
 }
 
 extern "C" int pt_render_finish(pt_context* c, pt_stats* stats) {
     if (!c) return PT_ERR_ARGUMENT;
-    if (!c->pending) return pt_fail(c, PT_ERR_ARGUMENT, "no render in flight");
+    const int slot_index = c->slot_oldest;
+    pt_context::Slot& sl = c->slot[slot_index];
+    if (!sl.pending) return pt_fail(c, PT_ERR_ARGUMENT, "no render in flight");
     PT_HIP(c, hipSetDevice(c->device));
-    PT_HIP(c, hipEventSynchronize(c->ev1));
-    c->pending = false;
-    int rc = pt_collect_stats(c, stats, c->pending_stats);
-    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->t_start).count();
+    PT_HIP(c, hipEventSynchronize(sl.copy_done));  // behind the kernels, ev1 and the copy of the flag / the counters
+    sl.pending = false;
+    c->slot_oldest = (slot_index + 1) % pt_context::PT_SLOTS;
+    int rc = pt_collect_stats(c, stats, slot_index);
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sl.t_start).count();
     return rc;
 }
 
@@ -1295,14 +1334,14 @@ extern "C" int pt_measure_copy_bandwidth(pt_context* c, uint64_t bytes, int iter
     const int per_cu[4] = {8, 16, 32, 64};
     for (int i = 0; i < 6 * iters + 1; i++) {
         const int form = i % 6;
-        PT_HIP(c, hipEventRecord(c->ev0, nullptr));
+        PT_HIP(c, hipEventRecord(c->slot[0].ev0, nullptr));
         if (form < 4) hipLaunchKernelGGL(pt_copy_kernel, dim3(c->n_cu * per_cu[form]), dim3(256), 0, nullptr, (const double2*)src, (double2*)dst, n);
         else if (form == 4) hipLaunchKernelGGL(pt_copy1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const double2*)src, (double2*)dst, n);
         else PT_HIP(c, hipMemcpyAsync(dst, src, n * 16, hipMemcpyDeviceToDevice, nullptr));
-        PT_HIP(c, hipEventRecord(c->ev1, nullptr));
-        PT_HIP(c, hipEventSynchronize(c->ev1));
+        PT_HIP(c, hipEventRecord(c->slot[0].ev1, nullptr));
+        PT_HIP(c, hipEventSynchronize(c->slot[0].ev1));
         float ms = 0.f;
-        PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        PT_HIP(c, hipEventElapsedTime(&ms, c->slot[0].ev0, c->slot[0].ev1));
         if (i > 0 && ms > 0.f) {
             const double rate = 2.0 * (double)(n * 16) / (ms * 1e-3) / 1e9;
             if (getenv("PORTRAYER_VERBOSE")) fprintf(stderr, "[pt_measure_copy_bandwidth] form %d: %.0f GB/s\n", form, rate);

@@ -1,4 +1,4 @@
-//! Declarations of the C ABI in include/portrayer_hip.h (PT_ABI_VERSION 6), field for field.
+//! Declarations of the C ABI in include/portrayer_hip.h (PT_ABI_VERSION 7), field for field.
 //! tests/test_integration_doc.py of the MI355X repository checks these structs against the header.
 #![allow(dead_code)]
 
@@ -7,7 +7,7 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct PtContext { _private: [u8; 0] }
 #[repr(C)] pub struct PtNode { _private: [u8; 0] }
 
-pub const PT_ABI_VERSION: c_int = 6;
+pub const PT_ABI_VERSION: c_int = 7;
 
 // enum Primitive, src/primitive.rs:67-81
 pub const PT_PRIM_SPHERE: i32 = 0;

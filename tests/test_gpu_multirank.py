@@ -183,6 +183,118 @@ def test_node_gather_through_rccl_with_one_rank(H, monkeypatch):
     lib.pt_node_destroy(node)
 
 
+@pytest.mark.parametrize("ranks,threads", [(3, "1"), (8, "1"), (4, "0")])
+def test_node_frames_in_a_pipeline(H, monkeypatch, ranks, threads):
+    """pt_node_frame_begin / pt_node_frame_end (ABI 7): two frames open at a time - frame k + 1 is rendered into the other set of tile
+    buffers while frame k is gathered and untiled on the gather streams, every rank launched by its own host thread (PORTRAYER_NODE_THREADS=0:
+    by the caller). Frames with DIFFERENT cameras, so that a frame assembled from the wrong buffer set cannot pass: every image == the
+    single-context render of its camera, a third begin without an end is refused, the stats are each frame's own."""
+    import device_glue
+    from example_scenes import EXAMPLES
+    from scene_dsl import Camera
+    monkeypatch.setenv("PORTRAYER_NODE_THREADS", threads)
+    scene, cam0, _ = EXAMPLES["macho-cows"]()
+    cams = [cam0] + [Camera(eye=(cam0.eye[0] + 0.7 * k, cam0.eye[1] + 0.3 * k, cam0.eye[2] - 0.5 * k), center=cam0.center, up=cam0.up, fovy_degrees=cam0.fovy_degrees) for k in (1, 2, 3, 4)]
+    ds = device_glue.DeviceScene(scene, H.TRAVERSE_FLAT)
+    lib = H.lib()
+    w, h = 200, 120
+    bg = default_background(w, h)
+    ctx = H.Context()
+    ds.upload(ctx)
+    singles = []
+    for cam in cams:
+        img, _, st1 = device_glue.render(ctx, cam, w, h, samples=2, seed=4, sample_mode=H.SAMPLE_RNG, stats=True)
+        singles.append((img, st1))
+    ctx.close()
+    node = C.c_void_p()
+    devs = (C.c_int32 * ranks)(*([0] * ranks))
+    assert lib.pt_node_create(ranks, devs, C.byref(node)) == 0
+    assert lib.pt_node_scene_upload(node, C.byref(ds.struct), H.TRAVERSE_FLAT, None) == 0, lib.pt_node_last_error(node)
+    p = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), 2, 4, H.SAMPLE_RNG, 1, 0, 1, 1)
+    assert lib.pt_node_upload_background(node, bg.ctypes.data_as(H._dp), C.byref(p), None) == 0, lib.pt_node_last_error(node)
+    cs = [device_glue.camera_struct(cam, w, h) for cam in cams]
+    st = H.PtStats()
+    hm = (C.c_double * 5)()
+
+    def check(k):  # close the oldest frame: it must be frame k
+        assert lib.pt_node_frame_end(node, C.byref(st)) == 0, lib.pt_node_last_error(node)
+        assert (st.primary, st.shadow, st.hits) == (singles[k][1]["primary"], singles[k][1]["shadow"], singles[k][1]["hits"]), k
+        assert lib.pt_node_last_frame_host_ms(node, C.byref(hm)) == 0 and hm[0] > 0.0 and hm[4] > 0.0
+
+    assert lib.pt_node_frame_end(node, None) != 0  # nothing open
+    assert lib.pt_node_frame_begin(node, C.byref(cs[0]), C.byref(p)) == 0, lib.pt_node_last_error(node)
+    assert lib.pt_node_frame_begin(node, C.byref(cs[1]), C.byref(p)) == 0, lib.pt_node_last_error(node)
+    assert lib.pt_node_frames_in_flight(node) == 2
+    assert lib.pt_node_frame_begin(node, C.byref(cs[2]), C.byref(p)) != 0  # a third open frame is refused ...
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    assert lib.pt_node_download_image(node, C.byref(p), img.ctypes.data_as(H._u8p)) != 0  # ... and so is reading the image under open frames
+    check(0)
+    for k in (2, 3, 4):  # begin k, close k - 1: always two open
+        assert lib.pt_node_frame_begin(node, C.byref(cs[k]), C.byref(p)) == 0, lib.pt_node_last_error(node)
+        check(k - 1)
+    check(4)
+    assert lib.pt_node_frames_in_flight(node) == 0
+    assert lib.pt_node_download_image(node, C.byref(p), img.ctypes.data_as(H._u8p)) == 0, lib.pt_node_last_error(node)
+    assert np.array_equal(img, singles[4][0]), "the last frame's image is not its camera's"
+    # and frame by frame: the image of every camera
+    for k in (1, 3, 0):
+        assert lib.pt_node_frame_begin(node, C.byref(cs[k]), C.byref(p)) == 0
+        check(k)
+        assert lib.pt_node_download_image(node, C.byref(p), img.ctypes.data_as(H._u8p)) == 0
+        assert np.array_equal(img, singles[k][0]), k
+    lib.pt_node_destroy(node)
+
+
+def test_node_rccl_leg_inside_a_process_that_carries_torch(H):
+    """bench.py drives pt_node from a process that has imported torch - which brings its own bundled RCCL - while pt_node dlopens the
+    system's librccl: the combination the driver's multi-GPU run uses and no test had executed. A subprocess (so that this
+    test process's own state does not matter) imports torch, initialises its CUDA side, then runs the one-rank RCCL leg of the node twice,
+    pipelined, and compares with the single-context image."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch
+assert torch.cuda.is_available()
+x = torch.ones(1024, device="cuda:0"); torch.cuda.synchronize()
+import torch.distributed  # (the process group machinery that loads torch's RCCL)
+import numpy as np
+os.environ["PORTRAYER_NODE_RCCL"] = "1"
+from portrayer_amd import _hip as H
+import device_glue
+from example_scenes import EXAMPLES
+from scene_dsl import default_background
+scene, cam, _ = EXAMPLES["primitives-simple"]()
+ds = device_glue.DeviceScene(scene, H.TRAVERSE_FLAT)
+lib = H.lib()
+w, h = 160, 96
+bg = default_background(w, h)
+ctx = H.Context(); ds.upload(ctx)
+one, _, _ = device_glue.render(ctx, cam, w, h, samples=2, seed=1, sample_mode=H.SAMPLE_RNG)
+ctx.close()
+node = C.c_void_p(); devs = (C.c_int32 * 1)(0)
+assert lib.pt_node_create(1, devs, C.byref(node)) == 0
+assert lib.pt_node_uses_rccl(node) == 1
+assert lib.pt_node_scene_upload(node, C.byref(ds.struct), H.TRAVERSE_FLAT, None) == 0
+p = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), 2, 1, H.SAMPLE_RNG, 1, 0, 1, 0)
+assert lib.pt_node_upload_background(node, bg.ctypes.data_as(H._dp), C.byref(p), None) == 0
+camera = device_glue.camera_struct(cam, w, h)
+assert lib.pt_node_frame_begin(node, C.byref(camera), C.byref(p)) == 0, lib.pt_node_last_error(node)
+assert lib.pt_node_frame_begin(node, C.byref(camera), C.byref(p)) == 0, lib.pt_node_last_error(node)
+assert lib.pt_node_frame_end(node, None) == 0 and lib.pt_node_frame_end(node, None) == 0, lib.pt_node_last_error(node)
+img = np.zeros((h, w, 3), dtype=np.uint8)
+assert lib.pt_node_download_image(node, C.byref(p), img.ctypes.data_as(H._u8p)) == 0
+assert np.array_equal(img, one)
+lib.pt_node_destroy(node)
+y = (x * 2).sum().item(); assert y == 2048.0   # torch's side still works afterwards
+print("rccl beside torch ok")
+""" % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl beside torch ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_host_renderer_on_a_node(host, H, monkeypatch):
     """PORTRAYER_DEVICES puts detail::Renderer (what Image::render builds) on a node: same picture."""
     sc = host.Scene.example("macho-cows", assets=ASSETS)
