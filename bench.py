@@ -130,9 +130,24 @@ def roofline_block(key, at_config_size, st, algorithmic, kernel_s, copy_gbps, co
     traffic = prof.get("hbm_bytes_per_launch") if prof else None
     f64, f32, flops = algorithmic_ops(counts, n_lights, traversal)
     achieved = (f64 + 0.5 * f32) / kernel_s / 1e12
+    # The tree step, told straight: `frac` credits a node visit with the TEXTBOOK two-box slab test - 36 f32 operations, counted as 18
+    # issue slots (as if every pair of them were one packed instruction). What the shipped step of the wave-uniform walks ISSUES per node visit:
+    # 6 packed fmas + 8 min / max + 3 compares = 17 instructions where the wavefront's rays share their direction signs (mesh-free scenes, plain
+    # kernel), 6 + 20 + 3 = 29 in the per-lane form (scenes with mesh instances). An instruction is one issue slot whatever its width on gfx950
+    # (a plain f32 instruction does not issue faster than an f64 one; only PACKED f32 doubles the work per slot), so the honest figure replaces
+    # 18 by 17 / 29; the third figure is what one gets by calling a shipped f32 instruction half a slot.
+    step_slots = None if traversal == "kd" else (17 if st["kernel_mode"] in (3, 6) else 29)
+    tree_step = None
+    if step_slots is not None:
+        n_in = counts["n_inner"]
+        tree_step = {"textbook_f32_ops_per_node_visit": 36, "counted_in_frac_as_issue_slots": 18, "shipped_instructions_per_node_visit": step_slots,
+                     "frac_with_the_shipped_step": (f64 + step_slots * n_in) / kernel_s / 1e12 / VALU_PEAK_TOPS,
+                     "frac_if_a_shipped_f32_instruction_were_half_a_slot": (f64 + 0.5 * step_slots * n_in) / kernel_s / 1e12 / VALU_PEAK_TOPS,
+                     "frac_f64_work_alone": f64 / kernel_s / 1e12 / VALU_PEAK_TOPS}
     return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s (f64-rate issue slots)", "frac": achieved / VALU_PEAK_TOPS,
             "traffic": traffic, "kernel": name, "kernel_ms": kernel_s * 1e3,
             "valu": {"f64_ops_per_launch": f64, "f32_ops_per_launch": f32, "flops_per_launch_fma_as_2": flops, "TFLOP_per_s_fma_as_2": flops / kernel_s / 1e12,
+                     "tree_step": tree_step,
                      "issued": ({"lanes_active_of_64": prof.get("lanes_active"), "valu_busy": prof.get("valu_busy"),
                                  "thread_cycles_valu_over_peak": prof.get("valu_issue_frac")} if prof else None)},
             "hbm": {"needed_bytes": needed_bytes, "measured_bytes": traffic, "waste_ratio": (traffic / needed_bytes) if traffic else None,

@@ -291,6 +291,8 @@ int pt_test_math(pt_context *ctx, int op, uint64_t n, const double *a, const dou
 /* (ABI 6) No GPU, no context: x[i]^y[i] by the HOST build of the kernels' pow (csrc/pt_pow.h) in `port` and by this machine's
  * libm in `libm` - the pin of the restated glibc algorithm against the library the reference calls. */
 int pt_test_pow_host(uint64_t n, const double *x, const double *y, double *port, double *libm);
+/* (ABI 7) the host's libm on explicit inputs (2 pow, 4 atan2, 5 acos): what device results are compared with */
+int pt_test_libm_host(int op, uint64_t n, const double *a, const double *b, double *out);
 /* Host-side replay (no GPU, no context) of how a launch with these parameters lays its work items and their 64 lanes over pixels,
  * chunks and samples - the kernel's own indexing code. Arrays of width x height, zeroed by the caller: samples carried per pixel,
  * the sum of their indices, the sum of the chunk lengths reported by the lanes that add a chunk up; optionally the number of work

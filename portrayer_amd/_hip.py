@@ -92,7 +92,7 @@ EXPORTS = ["pt_abi_version", "pt_device_count", "pt_context_create", "pt_context
            "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_synchronize", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
            "pt_test_math", "pt_test_work_items", "pt_node_create", "pt_node_destroy", "pt_node_last_error", "pt_node_ranks", "pt_node_uses_rccl", "pt_node_context",
            "pt_node_scene_upload", "pt_node_render", "pt_node_upload_background", "pt_node_render_resident", "pt_node_download_image",
-           "pt_node_device", "pt_node_frame_begin", "pt_node_frame_end", "pt_node_frames_in_flight", "pt_node_last_frame_host_ms", "pt_test_pow_host"]
+           "pt_node_device", "pt_node_frame_begin", "pt_node_frame_end", "pt_node_frames_in_flight", "pt_node_last_frame_host_ms", "pt_test_pow_host", "pt_test_libm_host"]
 
 
 def header_functions():
@@ -191,6 +191,8 @@ def lib() -> C.CDLL:
         l.pt_node_last_frame_host_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double * 5)]
         l.pt_test_pow_host.restype = C.c_int
         l.pt_test_pow_host.argtypes = [C.c_uint64, _dp, _dp, _dp, _dp]
+        l.pt_test_libm_host.restype = C.c_int
+        l.pt_test_libm_host.argtypes = [C.c_int, C.c_uint64, _dp, _dp, _dp]
         _lib = l
     return _lib
 

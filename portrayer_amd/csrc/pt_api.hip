@@ -145,10 +145,38 @@ __global__ void __launch_bounds__(256) pt_collapse4_kernel(const PtBvhNode* __re
     bvh4[i] = o;
 }
 
-// Second pass of a render: chunk sums -> pixels (one thread per pixel slot).
+// Second pass of a render: chunk sums -> pixels, a block of PT_BLOCK threads per PT_BLOCK pixel slots. The chunk sums are pixel-major (the
+// render kernel's chunk-first lanes write one pixel's sums side by side), so a thread per pixel would read 24 bytes every 24 x n_chunks
+// bytes; instead the block first adds them up EIGHT THREADS PER PIXEL - thread j of a pixel holds chunk 8 b + j of the b-th block of eight,
+// its seven neighbours' loads next to it, and the pixel's first thread adds the eight values in ascending order (the summation contract: a
+// fixed left-to-right association) - leaves the sums in LDS, and then finishes ONE pixel per thread (the three pows with every lane busy).
 __global__ void __launch_bounds__(PT_BLOCK) pt_finish_kernel(PtRenderArgs a) {
+#ifdef PT_ACCUM_CHUNK_MAJOR
     uint32_t p = blockIdx.x * PT_BLOCK + threadIdx.x;
-    if (p < a.n_slots) pt_finish_pixel(a, p);
+    if (p < a.n_slots) pt_finish_pixel(a, p, pt_pixel_sum(a, p));
+#else
+    __shared__ double sums[3 * PT_BLOCK];
+    const uint32_t base = blockIdx.x * PT_BLOCK, j = threadIdx.x & 7u;
+    for (uint32_t pass = 0; pass < 8u; pass++) {
+        const uint32_t local = pass * (PT_BLOCK / 8u) + (threadIdx.x >> 3), p = base + local;
+        PtVec3 sum = pt_v3(0.0, 0.0, 0.0);
+        for (uint32_t b = 0; b < a.n_chunks; b += 8u) {  // (wave-uniform trip count)
+            const uint32_t k = b + j;
+            PtVec3 v = pt_v3(0.0, 0.0, 0.0);
+            if (p < a.n_slots && k < a.n_chunks) { const double* c = a.accum + 3 * ((size_t)p * a.n_chunks + k); v = pt_v3(c[0], c[1], c[2]); }
+            const uint32_t n = a.n_chunks - b < 8u ? a.n_chunks - b : 8u;
+            for (uint32_t i = 0; i < n; i++) {  // chunk b + i of this pixel, from thread i of its eight
+                const int src = (int)((threadIdx.x & 63u & ~7u) + i);
+                const PtVec3 w = pt_v3(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src));
+                sum = (b == 0u && i == 0u) ? w : sum + w;
+            }
+        }
+        if (j == 0u) { sums[3 * local] = sum.x; sums[3 * local + 1] = sum.y; sums[3 * local + 2] = sum.z; }
+    }
+    __syncthreads();
+    const uint32_t p = base + threadIdx.x;
+    if (p < a.n_slots) pt_finish_pixel(a, p, pt_v3(sums[3 * threadIdx.x], sums[3 * threadIdx.x + 1], sums[3 * threadIdx.x + 2]));
+#endif
 }
 
 // compact (rank-major, tile-major) -> row-major image
@@ -1411,6 +1439,21 @@ extern "C" int pt_test_cast_rays(pt_context* c, uint64_t n, const double* origin
 extern "C" int pt_test_pow_host(uint64_t n, const double* x, const double* y, double* port, double* libm) {
     if (!x || !y || !port || !libm) return PT_ERR_ARGUMENT;
     for (uint64_t i = 0; i < n; i++) { port[i] = pt_pow_glibc(x[i], y[i]); libm[i] = pow(x[i], y[i]); }
+    return PT_OK;
+}
+
+// The HOST's libm (glibc: what the reference and the oracle call) on explicit inputs, op numbered like pt_test_math: 2 pow, 4 atan2, 5 acos.
+// (numpy's vectorised routines are not libm's on every machine: tests compare the device with this.)
+extern "C" int pt_test_libm_host(int op, uint64_t n, const double* a, const double* b, double* out) {
+    if (!a || !b || !out) return PT_ERR_ARGUMENT;
+    for (uint64_t i = 0; i < n; i++) {
+        switch (op) {
+        case 2: out[i] = pow(a[i], b[i]); break;
+        case 4: out[i] = atan2(a[i], b[i]); break;
+        case 5: out[i] = acos(a[i]); break;
+        default: return PT_ERR_ARGUMENT;
+        }
+    }
     return PT_OK;
 }
 

@@ -251,18 +251,18 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
             PtVec3 sum;
             if (FORK) {  // finished samples wait in the lanes' result slots in HBM (the LDS frames were reused by taken tasks)
                 sum = fr.h3(PT_RESULT_DEPTH, PT_H_MAIL);
-                for (uint32_t k = 1; k < it.count; k++) {
+                for (uint32_t k = 1; k < it.count && k < PT_SAMPLE_CHUNK; k++) {
                     const double* o = fr.spill + (size_t)k * (PT_SPILL_DEPTHS * PT_SPILL_STRIDE) + PT_RESULT_DEPTH * PT_SPILL_STRIDE + PT_H_MAIL;
                     sum = sum + pt_v3(o[0], o[1], o[2]);
                 }
             } else {
                 sum = fr.l3(PT_L_VALUE);
-                for (uint32_t k = 1; k < it.count; k++) {
+                for (uint32_t k = 1; k < it.count && k < PT_SAMPLE_CHUNK; k++) {  // (bounded by a constant as well: profiles/r04/notes.md, the hang of round 3's 6-wave build)
                     const double* o = fr.lds + k;
                     sum = sum + pt_v3(o[(PT_L_VALUE + 0) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 1) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 2) * PT_FRAME_STRIDE]);
                 }
             }
-            double* o = a.accum + 3 * ((size_t)(it.slot >> 6) * a.n_chunks * 64 + (size_t)it.chunk * 64 + (it.slot & 63u));
+            double* o = a.accum + 3 * ((size_t)it.slot * a.n_chunks + it.chunk);  // pixel-major: the chunk sums of a pixel side by side (see pt_finish_pixel)
             o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
         }
         __builtin_amdgcn_wave_barrier();

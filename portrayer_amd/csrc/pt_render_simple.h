@@ -387,11 +387,21 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
             const bool mine2 = pt_item_lane_fast(a, w, lane, &it, &x2, &y2);
             if (mine2 && it.first) {
                 PtVec3 sum = fr.l3(PT_L_VALUE);
+#ifdef PT_UNBOUNDED_CHUNK_LOOP  // (A/B only)
                 for (uint32_t k = 1; k < it.count; k++) {
+#else
+                for (uint32_t k = 1; k < it.count && k < PT_SAMPLE_CHUNK; k++) {  // (bounded by a constant as well: a corrupted count must not spin - profiles/r04/notes.md)
+#endif
                     const double* o = fr.lds + k;
                     sum = sum + pt_v3(o[(PT_L_VALUE + 0) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 1) * PT_FRAME_STRIDE], o[(PT_L_VALUE + 2) * PT_FRAME_STRIDE]);
                 }
+                // pixel-major: where a wavefront is one pixel (SAMPLES = 64) the eight chunk-first lanes' 24-byte stores fill one 192-byte run instead of eight
+                // lines 1,536 bytes apart (round 3: 0.97 GB HBM-side per big-scene frame for 0.45 GB of payload, the write granularity's doing)
+#ifdef PT_ACCUM_CHUNK_MAJOR  // (A/B only: round 3's layout)
                 double* o = a.accum + 3 * ((size_t)(it.slot >> 6) * a.n_chunks * 64 + (size_t)it.chunk * 64 + (it.slot & 63u));
+#else
+                double* o = a.accum + 3 * ((size_t)it.slot * a.n_chunks + it.chunk);
+#endif
                 o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
             }
         }

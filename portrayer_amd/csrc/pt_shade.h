@@ -138,7 +138,7 @@ struct PtRenderArgs {
     uint32_t k_log2, c_log2;         // K and C are powers of two: their logarithms, for pt_item_lane_fast
     PtFastDiv div_groups;            // by ceil(n_chunks / C): item -> (local tile, chunk group)
     PtFastDiv div_tiles_x;           // by the slice's tiles per row: tile -> (row, column)
-    double* accum;                   // n_slots x n_chunks x 3: per (tile, chunk, pixel) sum of the chunk's samples
+    double* accum;                   // n_slots x n_chunks x 3: per (pixel slot, chunk) the sum of the chunk's samples
     int32_t compact;                 // 1: rgb is tile-major over own tiles; 0: rgb is the full H x W x 3 image
     uint8_t* rgb;
     double* linear;                  // optional, same indexing as rgb
@@ -378,13 +378,23 @@ PT_HD bool pt_refracted_direction(PtVec3 ray_dir, PtVec3 normal, double eta, PtV
     return true;
 }
 
-// One pixel's chunk sums -> mean, gamma, clamp, u8 (render.rs:45-50, :143-147). p = pixel slot.
-PT_HD void pt_finish_pixel(const PtRenderArgs& a, uint32_t p) {
-    uint32_t x, y;
-    if (!pt_slot_to_pixel(a, p, &x, &y)) return;
+// A pixel's chunk sums added up in ascending order (the summation contract). p = pixel slot.
+PT_HD PtVec3 pt_pixel_sum(const PtRenderArgs& a, uint32_t p) {
+#ifdef PT_ACCUM_CHUNK_MAJOR
     const double* acc = a.accum + 3 * ((size_t)(p >> 6) * a.n_chunks * 64 + (p & 63));
     PtVec3 sum = pt_v3(acc[0], acc[1], acc[2]);
     for (uint32_t k = 1; k < a.n_chunks; k++) sum = sum + pt_v3(acc[192 * (size_t)k], acc[192 * (size_t)k + 1], acc[192 * (size_t)k + 2]);
+#else
+    const double* acc = a.accum + 3 * (size_t)p * a.n_chunks;  // the pixel's chunk sums, side by side
+    PtVec3 sum = pt_v3(acc[0], acc[1], acc[2]);
+    for (uint32_t k = 1; k < a.n_chunks; k++) sum = sum + pt_v3(acc[3 * (size_t)k], acc[3 * (size_t)k + 1], acc[3 * (size_t)k + 2]);
+#endif
+    return sum;
+}
+// One pixel's sum -> mean, gamma, clamp, u8 (render.rs:45-50, :143-147). p = pixel slot.
+PT_HD void pt_finish_pixel(const PtRenderArgs& a, uint32_t p, PtVec3 sum) {
+    uint32_t x, y;
+    if (!pt_slot_to_pixel(a, p, &x, &y)) return;
     PtVec3 color = sum / (double)a.samples;
     size_t idx = a.compact ? (size_t)p : (size_t)y * a.width + x;
     if (a.linear) { double* o = a.linear + 3 * idx; o[0] = color.x; o[1] = color.y; o[2] = color.z; }

@@ -19,6 +19,9 @@
 #include "pt_scene_view.h"
 
 #define PT_NO_HIT 0xFFFFFFFFu
+#ifndef PT_WALK_POPS_MAX
+#define PT_WALK_POPS_MAX (1u << 27)  // watchdog of the wave-uniform walks: more pending subtrees than the largest tree (2^26 nodes) has
+#endif
 #define PT_BLOCK 256              // threads per block of every traversal kernel = stride of the per-lane LDS columns
 #define PT_FRAME_STRIDE PT_BLOCK
 
@@ -1237,7 +1240,7 @@ PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRa
 // that reach it, which `in` follows).
 template <bool STATS, int OCT>
 PT_HD void pt_descend(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned long long lanes, unsigned long long self, uint32_t& cur, int& sp, unsigned long long& in,
-                      bool& overflowed, uint32_t* wstack, int words, PtCounters* cnt) {
+                      bool& overflowed, uint32_t* wstack, int words, uint32_t& pops, PtCounters* cnt) {
     constexpr int W = STATS ? 3 : 1;
     while (!(cur & PT_REF_LEAF)) {
         const pt_u32x16 v = pt_sload_node(bvh, cur);
@@ -1260,11 +1263,19 @@ PT_HD void pt_descend(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned
             }
         }
         if (code == 0u) {  // neither: the next pending subtree
+            // (the watchdog rides on the pops - a walk that goes on needs them, and they are rare next to the steps: a walk that has taken
+            // more pending subtrees than any tree this library accepts has nodes is a defect and ends like a stack overflow)
+#ifdef PT_WATCH_MESHFREE_DESCEND  // (measured: the counter inside the mesh-free walk's hand-tuned step costs 3.5 % on big-scene - 15 more spilled scalar
+            // registers, profiles/r04/notes.md; that walk keeps the count in its outer loop only, where a leaf has just been tested)
+            if (sp > 0 && ++pops <= PT_WALK_POPS_MAX) {
+#else
             if (sp > 0) {
+#endif
                 sp -= W;
                 next = PT_UNIFORM_U32(wstack[sp]);
                 if (STATS) in = (unsigned long long)PT_UNIFORM_U32(wstack[sp + 1]) | ((unsigned long long)PT_UNIFORM_U32(wstack[sp + 2]) << 32);
             } else {
+                overflowed = overflowed || sp > 0;
                 next = PT_REF_EMPTY;
             }
         }
@@ -1313,26 +1324,30 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     int sp = 0;                          // words on the stack
     constexpr int W = STATS ? 3 : 1;     // per entry: the node, and in the counting build the mask of the lanes that reach it
     const int words = wwords < W * sc.stack_cap ? wwords : W * sc.stack_cap;  // scene.stack_cap entries, if the LDS region holds them
+    uint32_t pops = 0;                   // (watchdog: pending subtrees taken by this walk, see pt_descend)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(pops));       // (kept in a scalar register: left to itself the compiler parks it in a vector register's lane and spills four more of those)
+#endif
     for (;;) {
-        bool overflowed = false;
+        bool overflowed = false;         // the stack overflowed or the watchdog tripped inside pt_descend
         if (!(cur & PT_REF_LEAF)) {
             const unsigned long long mine = amask;
             switch (STATS ? PT_OCT_MIXED : oct) {  // the counting build always takes the per-lane form (its images are compared with the plain build's)
-            case 0: pt_descend<STATS, 0>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
-            case 1: pt_descend<STATS, 1>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
-            case 2: pt_descend<STATS, 2>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
-            case 3: pt_descend<STATS, 3>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
-            case 4: pt_descend<STATS, 4>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
-            case 5: pt_descend<STATS, 5>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
-            case 6: pt_descend<STATS, 6>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
-            case 7: pt_descend<STATS, 7>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
-            default: pt_descend<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, cnt); break;
+            case 0: pt_descend<STATS, 0>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
+            case 1: pt_descend<STATS, 1>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
+            case 2: pt_descend<STATS, 2>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
+            case 3: pt_descend<STATS, 3>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
+            case 4: pt_descend<STATS, 4>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
+            case 5: pt_descend<STATS, 5>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
+            case 6: pt_descend<STATS, 6>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
+            case 7: pt_descend<STATS, 7>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
+            default: pt_descend<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, mine, self, cur, sp, in, overflowed, wstack, words, pops, cnt); break;
             }
         }
         if (cur == PT_REF_EMPTY) {
             if (overflowed) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                if (overflow) atomicOr(overflow, 1u);
+                if (overflow) atomicOr(overflow, pops > PT_WALK_POPS_MAX ? 4u : 1u);  // 4: the watchdog
 #endif
                 if (STATS) cnt->stack_overflow++;
                 if (has_ray) best.node = PT_NO_HIT;
@@ -1361,6 +1376,18 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
         sp -= W;
         cur = PT_UNIFORM_U32(wstack[sp]);
         if (STATS) in = (unsigned long long)PT_UNIFORM_U32(wstack[sp + 1]) | ((unsigned long long)PT_UNIFORM_U32(wstack[sp + 2]) << 32);
+#ifdef PT_WATCH_MESHFREE_WALK  // Off by default in THIS walk (on in the walks of scenes with meshes and in the k-d walk, where it measures nothing): three scalar
+        // instructions per pending subtree cost the headline 1.1 % (c16 / c22), and what they buy is little - a walk of a valid tree ends by itself (a node is
+        // entered at most once, pushes are bounded by the stack), and the one hang this code base has seen was not in a walk (profiles/r04/notes.md).
+        if (++pops > PT_WALK_POPS_MAX) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (overflow) atomicOr(overflow, 4u);
+#endif
+            if (STATS) cnt->stack_overflow++;
+            if (has_ray) best.node = PT_NO_HIT;
+            return;
+        }
+#endif
     }
 }
 
@@ -1389,9 +1416,10 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     int sp = 0;
     auto slot = [&](int k) -> uint32_t& { return wstack[k]; };
     const int words = wwords < sc.stack_cap ? wwords : sc.stack_cap;
+    uint32_t pops = 0;  // (watchdog: pending subtrees taken by this walk; one that takes more than any tree has nodes ends like a stack overflow)
     auto overflowed = [&]() {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (overflow) atomicOr(overflow, 1u);
+        if (overflow) atomicOr(overflow, pops > PT_WALK_POPS_MAX ? 4u : 1u);  // 4: the watchdog
 #endif
         if (STATS) cnt->stack_overflow++;
         if (has_ray) best.node = PT_NO_HIT;
@@ -1498,6 +1526,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
         // the next pending subtree; a marker ends the walk of a mesh instance
         for (;;) {
             if (sp == 0) return;
+            if (++pops > PT_WALK_POPS_MAX) { overflowed(); return; }
             sp--;
             cur = PT_UNIFORM_U32(slot(sp));
             if (cur != PT_REF_MARKER) break;

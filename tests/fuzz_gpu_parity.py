@@ -47,10 +47,10 @@ def extreme_scene(seed):
 MODES = os.environ.get("FUZZ_MODES", "flat,kd,hier").split(",")  # FUZZ_MODES=kd: only the k-d tree semantics
 
 
-def main():
-    first, count = int(sys.argv[1]), int(sys.argv[2])
-    w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (128, 96)
-    samples = int(sys.argv[5]) if len(sys.argv) > 5 else 2  # 2: 32 pixels x 2 samples per wavefront; 32: 2 pixels x 4 chunks x 8; 64: one pixel
+def run(first, count, w=128, h=96, samples=2, modes=None, out=print):
+    """`count` seeds from `first`: five scene families x the traversal semantics in `modes`, each scene rendered by the counting and by the plain
+    instantiation and compared with the oracle. Returns (differing pixels, tolerated texel-edge pixels of textured scenes, scenes x modes)."""
+    modes = MODES if modes is None else modes
     bad_total = 0
     tex_edge = 0
     n_renders = 0
@@ -62,7 +62,7 @@ def main():
             ps = O.pack(scene)
             hs = host_glue.host_scene(scene)
             for mode, tr, om in (("flat", H.TRAVERSE_FLAT, O.MODE_FLAT), ("kd", H.TRAVERSE_KD, O.MODE_KD), ("hier", H.TRAVERSE_HIER, O.MODE_HIER)):
-                if mode not in MODES:
+                if mode not in modes:
                     continue
                 n_renders += 1
                 r = host.Renderer(hs, tr, kd_depth=8)
@@ -71,20 +71,28 @@ def main():
                 plain, plain_linear, _ = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=samples, seed=seed, sample_mode=H.SAMPLE_RNG)  # the timed (non-counting) instantiation
                 if not np.array_equal(plain, rgb) or not np.array_equal(plain_linear, linear):
                     bad_total += 1
-                    print(f"MISMATCH seed {seed} {kind} {mode}: the counting and the plain instantiation render different images", flush=True)
+                    out(f"MISMATCH seed {seed} {kind} {mode}: the counting and the plain instantiation render different images")
                 bad = (rgb != ref.rgb).any(axis=2)
                 lin_bad = (linear.view(np.uint64) != ref.linear.view(np.uint64)).any(axis=2) & ~bad  # the device pow is glibc's: f64 means identical where the pixel is
                 if kind != "textured" and lin_bad.any():
                     bad_total += int(lin_bad.sum())
-                    print(f"MISMATCH seed {seed} {kind} {mode}: {int(lin_bad.sum())} pixels whose f64 mean differs in the last bits", flush=True)
+                    out(f"MISMATCH seed {seed} {kind} {mode}: {int(lin_bad.sum())} pixels whose f64 mean differs in the last bits")
                 if kind == "textured" and bad.sum() <= 2:  # sphere uv goes through atan2 / acos: a last-bit difference may move a sample across a texel edge
                     tex_edge += int(bad.sum()); bad[:] = False
                 rays_equal = all(st[k] == ref.stats[k] for k in ("primary", "shadow", "reflect", "refract", "hits"))
                 if bad.any() or not rays_equal or st["stack_overflow"]:
-                    bad_total += int(bad.sum())
-                    print(f"MISMATCH seed {seed} {kind} {mode}: {int(bad.sum())} pixels, rays_equal={rays_equal}, first {np.argwhere(bad)[:4].tolist()}, "
-                          f"kd_plane_miss gpu {st['kd_plane_miss']} oracle {ref.stats['kd_plane_miss']}", flush=True)
+                    bad_total += int(bad.sum()) + (0 if bad.any() else 1)
+                    out(f"MISMATCH seed {seed} {kind} {mode}: {int(bad.sum())} pixels, rays_equal={rays_equal}, first {np.argwhere(bad)[:4].tolist()}, "
+                        f"kd_plane_miss gpu {st['kd_plane_miss']} oracle {ref.stats['kd_plane_miss']}")
                 r.close()
+    return bad_total, tex_edge, n_renders
+
+
+def main():
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (128, 96)
+    samples = int(sys.argv[5]) if len(sys.argv) > 5 else 2  # 2: 32 pixels x 2 samples per wavefront; 32: 2 pixels x 4 chunks x 8; 64: one pixel
+    bad_total, tex_edge, n_renders = run(first, count, w, h, samples, out=lambda m: print(m, flush=True))
     print(f"fuzz done: seeds {first}..{first + count - 1} ({n_renders} scenes x modes, each the counting and the plain instantiation, {w}x{h}x{samples}), {bad_total} differing pixels in total ({tex_edge} texel-edge pixels in textured scenes tolerated)")
 
 

@@ -510,12 +510,15 @@ def test_hierarchical_rays_with_negative_zero_components(oracle, host, H):
     for tr, om in ((H.TRAVERSE_HIER, oracle.MODE_HIER), (H.TRAVERSE_FLAT, oracle.MODE_FLAT)):
         r = host.Renderer(host_glue.host_scene(scene), tr)
         rgb, linear, st = r.render(host_glue.cam10(cam), w, h, bg, stats=True)
+        plain, plain_linear, st1 = r.render(host_glue.cam10(cam), w, h, bg)  # the plain instantiation: the one with the per-octant tree steps
         r.close()
+        assert not st1["kernel_variant"] & H.KERNEL_COUNTING
         ref = oracle.render(oracle.pack(scene), cam, w, h, mode=om)
         for k in ("primary", "shadow", "hits"):
             assert st[k] == ref.stats[k], k
-        assert np.array_equal(rgb, ref.rgb)
+        assert np.array_equal(rgb, ref.rgb) and np.array_equal(plain, ref.rgb)
         assert_ulp(linear, ref.linear, 0)
+        assert_ulp(plain_linear, ref.linear, 0)
 
 
 @pytest.mark.parametrize("size", [(129, 97), (31, 47), (33, 15), (47, 31), (15, 33), (64, 64)])

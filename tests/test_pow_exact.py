@@ -31,7 +31,16 @@ def cpu_has_fma():
         return True
 
 
-pytestmark = pytest.mark.skipif(not cpu_has_fma(), reason="glibc selects its non-FMA pow on this CPU; pt_pow.h restates the FMA one")
+def glibc_version():
+    import platform
+    name, ver = platform.libc_ver()
+    return ver if name == "glibc" else ""
+
+
+# pt_pow.h restates ONE binary's pow: glibc 2.35's x86-64 FMA variant. On another glibc or a CPU without FMA the
+# machine's libm is a different function, and a failure here would say nothing about the port.
+pytestmark = [pytest.mark.skipif(not cpu_has_fma(), reason="glibc selects its non-FMA pow on this CPU; pt_pow.h restates the FMA one"),
+              pytest.mark.skipif(glibc_version() != "2.35", reason=f"pt_pow.h is pinned to glibc 2.35's pow; this machine has glibc {glibc_version() or '?'}")]
 
 
 def test_renderer_domain_is_bit_exact():
