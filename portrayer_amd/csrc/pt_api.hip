@@ -1052,10 +1052,10 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // Scenes whose hits spawn rays need the interpreter kernel (3 waves per SIMD); the others run the straight-line kernel at 3 or
     // 4 waves per SIMD. PORTRAYER_INTERP=1 (builds with -DPT_KEEP_INTERP): the interpreter on those too, for A/B runs.
     const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH || a.scene.mode == PT_MODE_KD_MESH;
-    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex) || c->four_waves_hier)) ? (c->five_waves ? 5 : 4) : 0;
+    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex) || c->four_waves_hier)) ? (c->five_waves ? PT_LINE_TOP_WAVES : 4) : 0;
     if (const char* e = getenv("PORTRAYER_WAVES")) {
         const int wv = atoi(e);
-        a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? 5 : 4) : 0;
+        a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? PT_LINE_TOP_WAVES : 4) : 0;
     }
     if (kd_sem) {
         // The k-d semantics: mesh-free scenes with many nodes take the 4-wave straight-line kernel too (big-scene 35.7 -> 30.7 ms: the per-lane
@@ -1080,7 +1080,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     if (const char* e = getenv("PORTRAYER_CHAIN")) chain = chain && atoi(e) > 0;  // 0: the interpreter kernel also for scenes whose recursion is a chain (A/B runs, tests)
     if (c->spawns) a.run_variant = (chain && a.park_slots) ? PT_RUN_CHAIN : (a.park_slots ? (fork ? PT_RUN_INTERP_FORK : PT_RUN_INTERP_PARK) : PT_RUN_INTERP);
     else if (pt_interpreter_forced()) a.run_variant = a.four_waves ? PT_RUN_INTERP4 : PT_RUN_INTERP;
-    else a.run_variant = a.four_waves == 5 ? PT_RUN_LINE5 : (a.four_waves ? PT_RUN_LINE4 : PT_RUN_LINE3);
+    else a.run_variant = a.four_waves >= 5 ? PT_RUN_LINE5 : (a.four_waves ? PT_RUN_LINE4 : PT_RUN_LINE3);  // (LINE5: the densest instantiation the mode has)
     if (a.run_variant == PT_RUN_CHAIN) {
         a.park_slots = 0;  // no frame in LDS: the parked colours go straight to the lane's HBM lines
         // 4 waves per SIMD in the flat_scene semantics (mirror scene 25.5 -> 26.8 Gray/s, c34: ten bounces per sample leave a lot of latency to hide),
@@ -1092,7 +1092,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
         if (const char* e = getenv("PORTRAYER_CHAIN_WAVES")) a.four_waves = (atoi(e) == 4 && a.scene.mode != PT_MODE_KD) ? 4 : 0;
         else if (a.scene.mode == PT_MODE_KD_MESH && !tex) a.four_waves = 4;
     }
-    size_t block_budget = a.four_waves == 5 ? 31 * 1024 : (a.four_waves ? 39 * 1024 : 52 * 1024);  // 3 x 52 KB, 4 x 39 KB or 5 x 31 KB of the CU's 160 KB
+    size_t block_budget = a.four_waves >= 6 ? 26 * 1024 : (a.four_waves == 5 ? 31 * 1024 : (a.four_waves ? 39 * 1024 : 52 * 1024));  // 3 x 52 KB, 4 x 39 KB, 5 x 31 KB or 6 x 26 KB of the CU's 160 KB
     if (const char* e = getenv("PORTRAYER_LDS_BUDGET_KB")) block_budget = (size_t)std::max(16, std::min(160, atoi(e))) * 1024;  // experiment: 80 = two blocks per CU
     const size_t frame_bytes = (size_t)(PT_LDS_FRAME_F64 + a.park_slots * PT_PARK_F64) * PT_BLOCK * 8;
     int lds_cap = block_budget > frame_bytes ? (int)((block_budget - frame_bytes) / (PT_BLOCK * 4)) : 0;

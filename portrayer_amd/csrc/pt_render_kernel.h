@@ -36,9 +36,6 @@
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 0  // experiments: -DPT_MIN_WAVES=2 / 3 / 4 for every instantiation
 #endif
-#ifndef PT_LINE_TOP_WAVES
-#define PT_LINE_TOP_WAVES 5  // waves per SIMD of the mesh-free straight-line kernels' densest instantiation (experiment: 6, with PORTRAYER_LDS_BUDGET_KB=26)
-#endif
 #ifndef PT_INTERP_WAVES
 #define PT_INTERP_WAVES 3  // experiments: -DPT_INTERP_WAVES=2 compiles the interpreter kernels (VAR 0, 1, 3) for 2 waves per SIMD (256 VGPRs)
 #endif
@@ -348,7 +345,8 @@ static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_
             if (a.four_waves == 4) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 4, true>>(lds, a, n_cu, stream, grid_out, launch);
         return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 3, true>>(lds, a, n_cu, stream, grid_out, launch);
     case PT_RUN_LINE5:  // mesh-free scenes in the flat_scene / hierarchical semantics: 96 registers, 5 waves per SIMD
-        if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH || MODE == PT_MODE_KD_NOMESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>>(lds, a, n_cu, stream, grid_out, launch);
+        if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>>(lds, a, n_cu, stream, grid_out, launch);
+        if constexpr (MODE == PT_MODE_KD_NOMESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 5>>(lds, a, n_cu, stream, grid_out, launch);  // (its saved range bounds want the LDS rows: 5 at most)
         [[fallthrough]];
     case PT_RUN_LINE4:  // the k-d tree semantics with mesh instances (per-lane walk through two levels of trees) have no 4-wave instantiation
         if constexpr (MODE != PT_MODE_KD) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 4>>(lds, a, n_cu, stream, grid_out, launch);

@@ -119,6 +119,12 @@ inline PtFastDiv pt_fastdiv_make(uint32_t d) {
 
 enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3 = 3, PT_RUN_INTERP4 = 4, PT_RUN_INTERP_FORK = 5, PT_RUN_LINE5 = 6, PT_RUN_CHAIN = 7 };  // PtRenderArgs::run_variant, explained in pt_render_kernel.h
 
+#ifndef PT_LINE_TOP_WAVES
+// Waves per SIMD of the mesh-free straight-line kernels' densest instantiation (flat_scene / hierarchical semantics): 6 since round 4 (80 registers, 26 KB of
+// LDS a block; big-scene +3.1 %, hierarchical +2.3 %, 3840x2160x256 +3.3 %: profiles/r04/notes.md section 5 - round 3 measured the same gain and could not ship
+// it because that build hung: section 2). -DPT_LINE_TOP_WAVES=5 builds round 3's.
+#define PT_LINE_TOP_WAVES 6
+#endif
 struct PtRenderArgs {
     PtSceneView scene;
     PtCamera cam;

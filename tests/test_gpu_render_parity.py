@@ -52,8 +52,8 @@ CASES = [("single-triangle", (256, 256), "flat"), ("single-triangle", (256, 256)
 
 
 @pytest.mark.parametrize("mode", ["flat", "hier"])
-def test_big_scene_five_wave_kernels_every_pixel(oracle, host, H, mode):
-    """The instantiations bench.py's headline and its default-semantics line run - the mesh-free straight-line kernel at 5 waves per SIMD, a
+def test_big_scene_densest_kernels_every_pixel(oracle, host, H, mode):
+    """The instantiations bench.py's headline and its default-semantics line run - the mesh-free straight-line kernel at 6 waves per SIMD (5 until round 3), a
     wavefront = one pixel's 64 samples - on a frame small enough for the oracle to render every pixel of: the plain (timed) instantiation and
     the counting one, image, f64 means and ray counts."""
     sc = host.Scene.example("big-scene", assets=ASSETS)
@@ -65,7 +65,7 @@ def test_big_scene_five_wave_kernels_every_pixel(oracle, host, H, mode):
     plain, plain_linear, st0 = r.render(sc.camera, w, h, bg, **kw)
     rgb, linear, st = r.render(sc.camera, w, h, bg, stats=True, **kw)
     r.close()
-    assert st0["kernel_variant"] == 5 and st0["kernel_mode"] == (6 if mode == "hier" else 3)
+    assert st0["kernel_variant"] == 6 and st0["kernel_mode"] == (6 if mode == "hier" else 3)  # the densest instantiation: 6 waves per SIMD since round 4
     cam = EXAMPLES["big-scene"]()[1]
     ref = oracle.render(oracle_from(oracle, sc), cam, w, h, samples=samples, seed=2, jitter=oracle.JITTER_RNG, mode=om)
     for k in ("primary", "shadow", "hits"):
