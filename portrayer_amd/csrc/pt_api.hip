@@ -219,6 +219,7 @@ struct pt_context {
     bool four_waves_hier = false;        // ... or any scene without KDMesh trees in the hierarchical semantics
     bool four_waves = false;   // traversal-heavy scene without reflective materials, flat_scene / hierarchical semantics: a kernel compiled for more than 3 waves per SIMD
     bool five_waves = false;   // ... mesh-free: 5 waves per SIMD (96 registers)
+    bool five_waves_mesh = false;  // ... very many triangles in plain Mesh instances, untextured: 5 waves too
     PtSceneView view;
     bool have_scene = false;
     // Up to PT_SLOTS renders of one context may be in flight on a stream (pt_render_device ... pt_render_finish, oldest first): a frame's
@@ -787,6 +788,9 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         // mesh-free scenes go one further: 5 waves per SIMD (96 registers, 17 of the kernel's spilled; big-scene 34.4 -> 37.0, hierarchical
         // 29.4 -> 32.5 Gray/s; the k-d walk, 50 spilled, loses and stays at 4)
         c->five_waves = c->four_waves && s->n_meshes == 0 && traverse != PT_TRAVERSE_KD;
+        // ... and so do scenes of very many triangles in plain Mesh instances (round 4, c29: their walks wait for node fetches - 3 -> 4 waves was +18 % -; the 1.25 M-triangle
+        // scenes +3.7 % / +3.2 %, hierarchical +2.6 %, at 96 registers with 57 spilled; macho-cows, 17,500 triangles, loses 15 % and stays at 4)
+        c->five_waves_mesh = !c->spawns && plain_meshes && instanced_tris >= 65536 && (traverse == PT_TRAVERSE_FLAT || traverse == PT_TRAVERSE_HIER);
     }
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
     {   // fork / join of refracted subtrees (pt_shade.h) needs a recursion that draws no random numbers and a dielectric material to be of use
@@ -1052,10 +1056,10 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // Scenes whose hits spawn rays need the interpreter kernel (3 waves per SIMD); the others run the straight-line kernel at 3 or
     // 4 waves per SIMD. PORTRAYER_INTERP=1 (builds with -DPT_KEEP_INTERP): the interpreter on those too, for A/B runs.
     const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH || a.scene.mode == PT_MODE_KD_MESH;
-    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex) || c->four_waves_hier)) ? (c->five_waves ? PT_LINE_TOP_WAVES : 4) : 0;
+    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex) || c->four_waves_hier)) ? (c->five_waves ? PT_LINE_TOP_WAVES : ((c->five_waves_mesh && !tex) ? 5 : 4)) : 0;
     if (const char* e = getenv("PORTRAYER_WAVES")) {
         const int wv = atoi(e);
-        a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? PT_LINE_TOP_WAVES : 4) : 0;
+        a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? PT_LINE_TOP_WAVES : ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_HIER_MESH)) ? 5 : 4)) : 0;
     }
     if (kd_sem) {
         // The k-d semantics: mesh-free scenes with many nodes take the 4-wave straight-line kernel too (big-scene 35.7 -> 30.7 ms: the per-lane
