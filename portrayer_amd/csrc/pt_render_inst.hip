@@ -2,9 +2,14 @@
 // the variants listed in pt_render_kernel.h) and their launcher. Compiled once per mode: -DPT_INST_MODE=1..8 (Makefile).
 // The texture routine (pt_apply_maps) is out of line so that untextured hits keep their register budget - except in the flat_scene
 // kernels of scenes with KDMesh trees, where inlining it measured +10 % (transmission-refraction 11.5 -> 12.6 Gray/s; the same scene
-// in the hierarchical semantics loses 7 % inlined: profiles/r03/notes.md section 4).
-#if defined(PT_INST_MODE) && PT_INST_MODE == 4 && !defined(PT_MAPS_INLINE)
+// in the hierarchical semantics loses 7 % inlined: profiles/r03/notes.md section 4). In that instantiation the interpreter also applies
+// the maps BEFORE it enters its state machine (PT_MAPS_BEFORE, round 4: 12.9 -> 13.6 Gray/s, 148 -> 95 GB HBM-side per frame; the
+// hierarchical instantiation loses 4 % that way and keeps the call inside pt_hit_surface: profiles/r04/notes.md section 6).
+#if defined(PT_INST_MODE) && PT_INST_MODE == 4 && !defined(PT_MAPS_INLINE) && !defined(PT_MAPS_OUT_OF_LINE)
 #define PT_MAPS_INLINE
+#endif
+#if defined(PT_INST_MODE) && PT_INST_MODE == 4 && !defined(PT_MAPS_BEFORE) && !defined(PT_MAPS_INSIDE)
+#define PT_MAPS_BEFORE
 #endif
 #include "pt_render_kernel.h"
 #include "pt_render_inst.h"

@@ -153,7 +153,17 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 #ifndef PT_NO_ARGS_AGAIN
             const PtRenderArgs& a = pt_args_again(a0);  // what the interpreter and this pass's walk need of the arguments is fetched now, not kept from the top of the kernel on (pt_render_simple.h)
 #endif
-            if (active) pt_lane_advance<STATS, TEX, MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH || MODE == PT_MODE_HIER_MESH, PARK, FORK>(a, L, hit, fr, &cnt);
+            constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH || MODE == PT_MODE_HIER_MESH;
+            uint32_t pre = 0;
+#ifdef PT_MAPS_BEFORE
+            if (TEX) {
+                // Hits whose material has a texture or a normal map: the maps are applied here, outside the state machine (whose
+                // registers would otherwise be spilled around the map code on every pass), for the lanes that need them.
+                const bool maps = active && L.stage == PT_ST_CLOSEST_DONE && pt_hit_has_maps(a.scene, hit);
+                if (__any(maps)) { if (maps) pre = pt_lane_maps<HIER>(a.scene, L.ray, hit, fr); }
+            }
+#endif
+            if (active) pt_lane_advance<STATS, TEX, HIER, PARK, FORK>(a, L, hit, fr, &cnt, pre);
             if (FORK) {
                 // Offers and takers, matched by rank: the k-th lane that parked a frame with a refracted ray in this pass writes its
                 // thread index to slot k of the wavefront's queue in LDS (the first words of its traversal stack, free between

@@ -88,6 +88,8 @@ enum { PT_FS_WAIT_REFLECT = 1, PT_FS_WAIT_REFRACT = 2, PT_FS_STAGE_MASK = 3, PT_
 // A finished sample's colour waits in slots 12..14 of the lane's depth-10 line (frames of depth 10 never spawn, so that mailbox is
 // free): the lane's LDS frame is reused by the tasks it takes.
 enum { PT_H_MAIL = 12, PT_H_MAIL_TICKET = 15, PT_RESULT_DEPTH = PT_MAX_DEPTH };
+#define PT_PRE_MAPS 0x40000000u   // pt_lane_maps ran for this hit; PT_PRE_NORMAL: it left the normal map's shading normal in the frame's PT_L_N
+#define PT_PRE_NORMAL 0x20000000u
 #define PT_FS_TEXEL 0x80000000u  // hit frame: bits 0..23 are the texel's R, G, B bytes; the diffuse colour is srgb_lut[] of them (texture.rs:162-168)
 #define PT_LIGHT_ROUND 32  // shadow-ray results are kept as one bit per light, 32 lights at a time
 
@@ -550,11 +552,11 @@ PT_MAPS_ATTR PtMapsOut pt_apply_maps(const PtTexView* view, uint32_t mat, uint32
 
 // flat_scene.rs:85-95 / scene.rs:100-112 + material.rs:109-144 for the winning candidate of a ray: the model-space hit is rebuilt
 // with the reference's expressions, point and normal go to world space (HIER: level by level), the material's maps are applied.
-// Out: world-space point P, shading normal N (normalised geometric normal, or the normal map's), material index, texel tag.
-template <bool TEX, bool HIER>
-PT_HD void pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& hit, PtVec3* P_out, PtVec3* N_out, uint32_t* mat_out, uint32_t* ftag_out) {
+// The hit in the node's model space: its point p and raw normal n, the ray there, the node's type and material.
+template <bool HIER>
+PT_HD void pt_hit_model(const PtSceneView& sc, const PtRay& ray, const PtHit& hit, uint32_t* type_out, uint32_t* mat_out, PtRay* local_out, PtVec3* p_out, PtVec3* n_out) {
     const uint32_t* info = sc.info + 4 * (size_t)hit.node;
-    uint32_t type = info[0], flags = info[2], mat = info[3];
+    uint32_t type = info[0], flags = info[2];
     PtRay local = pt_node_local_ray<HIER>(sc, hit.node, ray);
     PtVec3 p, n;
     if (type == PT_TRIANGLE || type == PT_MESH || type == PT_KDMESH) {
@@ -574,6 +576,19 @@ PT_HD void pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& 
     } else {
         pt_prim_surface(type, hit.sub, local, hit.t, &p, &n);
     }
+    *type_out = type; *mat_out = info[3]; *local_out = local; *p_out = p; *n_out = n;
+}
+
+// Out: world-space point P, shading normal N (normalised geometric normal, or the normal map's), material index, texel tag.
+// MAPS_LATER (the interpreter kernel): a material's texture / normal map is NOT applied here - pt_lane_maps has done it for the
+// lane before the state machine was entered (the map code then sits outside the state machine, where the registers it needs
+// are spilled around it and not around every pass: profiles/r04/notes.md section 6). Returns true when the material has a map.
+template <bool TEX, bool HIER, bool MAPS_LATER = false>
+PT_HD bool pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& hit, PtVec3* P_out, PtVec3* N_out, uint32_t* mat_out, uint32_t* ftag_out) {
+    uint32_t type, mat;
+    PtRay local;
+    PtVec3 p, n;
+    pt_hit_model<HIER>(sc, ray, hit, &type, &mat, &local, &p, &n);
     PT_FENCE;
     PtVec3 P, Nw;
     if (HIER) {  // scene.rs:100-101, :111-112: every level on the way up applies its own trans / normal_trans
@@ -598,13 +613,19 @@ PT_HD void pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& 
     }
     PtVec3 N = pt_normalized(Nw);  // material.rs:123-125
     uint32_t ftag = 0;
+    bool later = false;
     if (TEX && sc.mat_maps && (sc.mat_maps[2 * mat] >= 0 || sc.mat_maps[2 * mat + 1] >= 0)) {  // material.rs:109-144
-        PtMapsOut mo = pt_apply_maps(sc.texview, mat, type, hit.sub, local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z,
-                                     p.x, p.y, p.z, n.x, n.y, n.z);
-        if (mo.has_n) N = pt_v3(mo.n[0], mo.n[1], mo.n[2]);
-        ftag = mo.texel;
+        if (MAPS_LATER) {
+            later = true;
+        } else {
+            PtMapsOut mo = pt_apply_maps(sc.texview, mat, type, hit.sub, local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z,
+                                         p.x, p.y, p.z, n.x, n.y, n.z);
+            if (mo.has_n) N = pt_v3(mo.n[0], mo.n[1], mo.n[2]);
+            ftag = mo.texel;
+        }
     }
     *P_out = P; *N_out = N; *mat_out = mat; *ftag_out = ftag;
+    return later;
 }
 
 // material.rs:179-210 for one light that is not occluded: (diffuse + specular) / attenuation. lcol = the light's colour,
@@ -662,8 +683,27 @@ PT_HD void pt_mail_store(double* slot, uint64_t v) {
 #endif
 }
 
+// The texture / normal map of the hit the lane is about to shade (material.rs:109-144), applied BEFORE pt_lane_advance runs its
+// PT_ST_CLOSEST_DONE: returns PT_PRE_MAPS | the texel tag (| PT_PRE_NORMAL with the shading normal in the frame's PT_L_N slots).
+// The hit's model-space point and normal are worked out here and again in pt_hit_surface - the same operations, the same bits.
+PT_HD bool pt_hit_has_maps(const PtSceneView& sc, const PtHit& hit) {
+    if (hit.node == PT_NO_HIT || !sc.mat_maps) return false;
+    const uint32_t mat = sc.info[4 * (size_t)hit.node + 3];
+    return sc.mat_maps[2 * mat] >= 0 || sc.mat_maps[2 * mat + 1] >= 0;
+}
+template <bool HIER>
+PT_HD uint32_t pt_lane_maps(const PtSceneView& sc, const PtRay& ray, const PtHit& hit, const PtFrameRef& fr) {
+    uint32_t type, mat;
+    PtRay local;
+    PtVec3 p, n;
+    pt_hit_model<HIER>(sc, ray, hit, &type, &mat, &local, &p, &n);
+    PtMapsOut mo = pt_apply_maps(sc.texview, mat, type, hit.sub, local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z, p.x, p.y, p.z, n.x, n.y, n.z);
+    if (mo.has_n) fr.set_l3(PT_L_N, pt_v3(mo.n[0], mo.n[1], mo.n[2]));
+    return PT_PRE_MAPS | (mo.has_n ? PT_PRE_NORMAL : 0u) | mo.texel;
+}
+
 template <bool STATS, bool TEX, bool HIER = false, int PARK = 0, bool FORK = false>
-PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt) {
+PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtHit& hit, const PtFrameRef& fr, PtCounters* cnt, uint32_t pre = 0) {
     const PtSceneView& sc = a.scene;
     L.has_ray = false;
     PtVec3 value = pt_v3(0.0, 0.0, 0.0);  // colour being returned to the parent frame
@@ -771,10 +811,15 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             if (STATS) cnt->hits++;
             PtVec3 P, N;
             uint32_t mat, ftag;
+#ifdef PT_MAPS_BEFORE
+            pt_hit_surface<TEX, HIER, true>(sc, L.ray, hit, &P, &N, &mat, &ftag);
+#else
             pt_hit_surface<TEX, HIER>(sc, L.ray, hit, &P, &N, &mat, &ftag);
+#endif
             fr.set_l3(PT_L_P, P);
             PT_FENCE;
-            fr.set_l3(PT_L_N, N);
+            if (TEX && (pre & PT_PRE_MAPS)) ftag = pre & (PT_FS_TEXEL | 0xFFFFFFu);  // pt_lane_maps ran for this hit
+            if (!(TEX && (pre & PT_PRE_NORMAL))) fr.set_l3(PT_L_N, N);                // (else the normal map's normal is already there)
             fr.set_l3(PT_L_D, L.ray.d);
             fr.l(PT_L_TAG) = PtFrameRef::pack_tag(mat, ftag);
             L.light = 0;
