@@ -227,6 +227,36 @@ PT_HD bool pt_triangle_hit(const double* v, const PtRay& r, double start, double
     return true;
 }
 
+// The same test from the triangle's EDGE record (PtSceneView::tri_e: corner a, then a - b and a - c, the six differences above
+// taken once on the host - the same IEEE subtractions, the same bits). In the walks that hold the record in scalar registers this
+// saves the six subtractions and the moves that bring their second operands into vector registers, for every triangle tested.
+PT_HD bool pt_triangle_hit_e(const double* te, const PtRay& r, double start, double end, double* t_out, double* beta_out, double* gamma_out) {
+    double a = te[3], b = te[4], c = te[5];
+    double d = te[6], e = te[7], f = te[8];
+    double g = r.d.x, h = r.d.y, i = r.d.z;
+    double j = te[0] - r.o.x, k = te[1] - r.o.y, l = te[2] - r.o.z;
+
+    double ei_hf = e * i - h * f;
+    double gf_di = g * f - d * i;
+    double dh_eg = d * h - e * g;
+    double m = a * ei_hf + b * gf_di + c * dh_eg;
+
+    double ak_jb = a * k - j * b;
+    double jc_al = j * c - a * l;
+    double bl_ck = b * l - c * k;
+
+    double t = -(f * ak_jb + e * jc_al + d * bl_ck) / m;
+    if (!pt_in_range(start, end, t)) return false;
+    double gamma = (i * ak_jb + h * jc_al + g * bl_ck) / m;
+    if (gamma < 0.0 || gamma > 1.0) return false;
+    double beta = (j * ei_hf + k * gf_di + l * dh_eg) / m;
+    if (beta < 0.0 || beta > 1.0 - gamma) return false;
+    *t_out = t;
+    *beta_out = beta;
+    *gamma_out = gamma;
+    return true;
+}
+
 // bounding_box.rs:104-116: `inv` = rows 0..2 of the box's unit-cube inverse transform
 PT_HD bool pt_bbox_test_hit(const double* inv, const PtRay& r, double start, double end) {
     PtRay local = pt_ray_to_local(inv, r);

@@ -97,6 +97,7 @@ struct PtSceneView {
     const double* nrm;
     const uint32_t* info;
     const double* tri_v;
+    const double* tri_e;   // n_tris x 9 f64: corner a, a - b, a - c (pt_triangle_hit_e): what the wave-uniform walks test triangles from
     const double* tri_n;
     const PtMeshInfo* meshes;
     const double* materials;
@@ -106,6 +107,7 @@ struct PtSceneView {
     const PtBvh4Node* bvh4;   // its four-child form, same node indices
     const uint32_t* bvh_items;
     uint32_t tlas_root;
+    uint32_t mesh_oct;     // 1: inside mesh instances the triangle trees are walked with the octant-sorted slab test (pt_trace_packet_mesh; PORTRAYER_MESH_OCT=0 turns it off)
     uint32_t tlas_direct;  // 1: a leaf of the scene-level tree names its flattened node in the reference itself (bits 30..3)
     const PtKdNode* kd;
     const uint32_t* kd_items;

@@ -1033,6 +1033,13 @@ PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, cons
 // bit a set: they all enter slabs of axis a through the UPPER plane (negative direction), clear: through the lower one; PT_OCT_MIXED
 // when some axis has rays of both signs among those lanes. Rays through one pixel, or from neighbouring points to one light,
 // nearly always share their signs, and then the tree step needs no min / max to tell entering from leaving (pt_slab_pk2).
+#ifdef PT_NO_TRI_EDGES  // A/B: the wave-uniform walks test triangles from their corners again
+#define PT_TRI_REC(sc) (sc).tri_v
+#define PT_TRI_HIT pt_triangle_hit
+#else
+#define PT_TRI_REC(sc) (sc).tri_e
+#define PT_TRI_HIT pt_triangle_hit_e
+#endif
 #define PT_OCT_MIXED 8
 PT_HD PtRayPk pt_raypk(const PtRay& r, bool lanes, int* oct) {
     PtRayPk q;
@@ -1409,6 +1416,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     unsigned long long pmask = PT_BALLOT(alive && part);  // the lanes the slab test's results count for, as a wave-uniform mask
     PtRay local = ray;        // the ray in the space of the tree being walked
     PtRayPk q = pt_raypk(ray);
+    int oct = PT_OCT_MIXED;   // wave-uniform: the octant the participating lanes' rays share inside the mesh instance being walked, if they do (sc.mesh_oct)
     const bool identity_ok = HIER && pt_ray_identity_safe(ray, has_ray);  // (wave-uniform) levels of a path that are the identity may be skipped
     float tm = INFINITY;      // best.t as the f32 bound of the slab test (t means the same in every space, ray.rs:130-135)
     uint32_t inst = PT_NO_HIT;  // wave-uniform: flat node of the mesh instance being walked
@@ -1429,7 +1437,21 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
         // stack overflowed. Always the per-lane form of the slab test: the walks of these scenes are short (5.7 tree steps per ray on
         // macho-cows, 8.6 on the mirror scene) and the octant bookkeeping per ray and per mesh instance cost more than the eight
         // instructions per step it saves (cows -6 %, mirror -3 %; big-scene, mesh-free, +4 %: profiles/r03/notes.md).
-        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt);
+        // Round 4 (sc.mesh_oct): INSIDE a mesh instance whose lanes' rays share their direction signs the sorted form runs (`oct`, worked out once per
+        // instance entered; the scene-level steps keep the per-lane form): 37 steps per ray on the 1.25 M-triangle soup +6 %, the short walks no longer lose.
+        if (!(cur & PT_REF_LEAF)) {
+            switch (STATS ? PT_OCT_MIXED : oct) {
+            case 0: pt_descend_mesh<STATS, 0>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 1: pt_descend_mesh<STATS, 1>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 2: pt_descend_mesh<STATS, 2>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 3: pt_descend_mesh<STATS, 3>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 4: pt_descend_mesh<STATS, 4>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 5: pt_descend_mesh<STATS, 5>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 6: pt_descend_mesh<STATS, 6>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 7: pt_descend_mesh<STATS, 7>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            default: pt_descend_mesh<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            }
+        }
         if (cur == PT_REF_EMPTY) { overflowed(); return; }
         const bool popped = cur == PT_REF_POP;
         if (!popped) {
@@ -1439,7 +1461,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
             if (inst != PT_NO_HIT) {  // triangles of the mesh being walked
                 for (uint32_t i = 0; i < count; i++) {
                     const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[first + i]);
-                    const double* rec = sc.tri_v + 9 * (size_t)tri;
+                    const double* rec = PT_TRI_REC(sc) + 9 * (size_t)tri;
                     pt_u32x16 a;
                     uint32_t b0, b1;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1460,7 +1482,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                     if (alive && part) {
                         double tt, beta, gamma;
                         if (STATS) cnt->n_tri++;
-                        if (pt_triangle_hit(tv, local, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, inst, tri), &tt, &beta, &gamma)) {
+                        if (PT_TRI_HIT(tv, local, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, inst, tri), &tt, &beta, &gamma)) {
                             best.t = tt; best.node = inst; best.sub = tri;
                             tm = pt_tmax32(tt);
                             if (any) alive = false;
@@ -1508,7 +1530,8 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         if (i + 1 < count) { slot(sp) = PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2); sp++; }  // the rest of this leaf
                         slot(sp) = PT_REF_MARKER; sp++;
                         local = lr; part = inside; inst = node;
-                        q = pt_raypk(lr);
+                        if (sc.mesh_oct) q = pt_raypk(lr, inside, &oct);
+                        else q = pt_raypk(lr);
                         cur = root;
                         entered = true;
                     } else if (alive) {
@@ -1531,7 +1554,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
             cur = PT_UNIFORM_U32(slot(sp));
             if (cur != PT_REF_MARKER) break;
             inst = PT_NO_HIT; local = ray; part = has_ray;
-            q = pt_raypk(ray);
+            q = pt_raypk(ray); oct = PT_OCT_MIXED;
             pmask = PT_BALLOT(alive && part);
         }
     }
@@ -1748,7 +1771,7 @@ PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_
             if (STATS && part) cnt->n_leaf++;
             for (uint32_t i = 0; i < count; i++) {
                 const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[first + i]);
-                const double* rec = sc.tri_v + 9 * (size_t)tri;
+                const double* rec = PT_TRI_REC(sc) + 9 * (size_t)tri;
                 pt_u32x16 a;
                 uint32_t b0, b1;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1769,7 +1792,7 @@ PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_
                 if (part) {
                     double tt, beta, gamma;
                     if (STATS) cnt->n_tri++;
-                    if (pt_triangle_hit(tv, local, start, pt_cand_end(lb, inst, tri), &tt, &beta, &gamma)) {
+                    if (PT_TRI_HIT(tv, local, start, pt_cand_end(lb, inst, tri), &tt, &beta, &gamma)) {
                         lb.t = tt; lb.node = inst; lb.sub = tri;
                         found = true;
                         tm = pt_tmax32(tt);
