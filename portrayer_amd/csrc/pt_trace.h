@@ -1459,6 +1459,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
             PT_WAVE_COUNT(5);
             if (STATS && alive && part) cnt->n_leaf++;
             if (inst != PT_NO_HIT) {  // triangles of the mesh being walked
+                PT_CYC_BEGIN();
                 for (uint32_t i = 0; i < count; i++) {
                     const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[first + i]);
                     const double* rec = PT_TRI_REC(sc) + 9 * (size_t)tri;
@@ -1489,6 +1490,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         }
                     }
                 }
+                PT_CYC_END(5);
             } else {
                 bool entered = false;
                 for (uint32_t i = 0; i < count && !entered; i++) {
@@ -1679,43 +1681,7 @@ PT_HD pt_u32x16 pt_sload16_off(const void* base, uint32_t byte_off) {
     return v;
 }
 
-// ---- f64 division by a denominator that is divided by again and again (a ray's direction component: every straddled split of a
-// k-d walk computes (plane - o) / d, node.rs:90-109).
-// The compiler expands an IEEE f64 division into: v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 fma), q0 = n y,
-// r = fma(-d, q0, n), q1 = v_div_fmas(r, y, q0), v_div_fixup. For operands in the normal range v_div_scale returns its operand
-// unchanged (and clears VCC, so v_div_fmas is a plain fma) and v_div_fixup returns q1 unchanged: the quotient IS
-// fma(fma(-d, n y, n), y, n y) with y = the twice-refined reciprocal of d - a function of d alone. pt_rcp_refined() computes that y
-// with the very instructions of the expansion, once per ray and axis; pt_div_fast() finishes a division in three instructions, bit
-// for bit the hardware sequence's result (not by an error analysis: by being the same operations on the same operands).
-// "Normal range" (V_DIV_SCALE_F64 / V_DIV_FIXUP_F64 in the CDNA ISA guide): both operands finite and non-zero, d and 1 / d normal,
-// exponent(n) - exponent(d) in (-1022, 768), exponent(n) > 53. pt_div_exp_ok() is a sufficient test: the biased exponent in
-// [640, 1407], i.e. 2^-383 <= |x| < 2^385; anything else - zeros, denormals, infinities, NaNs included - takes the real division.
-// Checked against `/` on the device over the whole window and its edges (tests/test_gpu_device_parity.py).
-PT_HD double pt_rcp_refined(double d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double y0 = __builtin_amdgcn_rcp(d);
-    const double e0 = __builtin_fma(-d, y0, 1.0);
-    const double y1 = __builtin_fma(y0, e0, y0);
-    const double e1 = __builtin_fma(-d, y1, 1.0);
-    return __builtin_fma(y1, e1, y1);
-#else
-    return 1.0 / d;
-#endif
-}
-PT_HD bool pt_div_exp_ok(double x) {
-    union { double d; uint32_t u[2]; } c; c.d = x;
-    return (((c.u[1] >> 20) & 0x7FFu) - 640u) <= 767u;
-}
-PT_HD double pt_div_fast(double n, double d, double y) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double q0 = n * y;
-    const double r = __builtin_fma(-d, q0, n);
-    return __builtin_fma(r, y, q0);
-#else
-    (void)y;
-    return n / d;
-#endif
-}
+// (pt_rcp_refined / pt_div_exp_ok / pt_div_fast - the short f64 division by a repeated denominator - live in pt_math.h)
 
 struct PtKdSav {
     uint32_t* lds;        // the wavefront's rows for saved bounds: slot j, half h of lane l at lds[(2 j + h) * 64 + l]
