@@ -1,0 +1,84 @@
+"""Register budgets of the shipped render-kernel instantiations, read from the code objects' metadata (no GPU needed).
+
+The launcher picks a kernel by the number of wavefronts per SIMD it was compiled for (`pt_api.hip`: 3, 4, 5 or 6 = 168, 128, 96 or
+80 vector registers); an instantiation that outgrows its budget silently loses occupancy, and one that starts to spill far more than
+it did is the first sign of a change that costs HBM traffic (`profiles/r04/notes.md` sections 2, 5 and 6: the 80-register build and
+the textured interpreter). The ceilings below are the committed tree's counts plus some slack; raise them knowingly.
+"""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "portrayer_amd", "csrc")
+LLVM = "/opt/rocm/lib/llvm/bin"
+BUDGET = {3: 168, 4: 128, 5: 96, 6: 80}
+
+
+def kernels_of(mode):
+    obj = os.path.join(CSRC, "pt_render_m%d.o" % mode)
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(LLVM, "llvm-readelf")):
+        pytest.skip("no device object / llvm tools here: run __graft_entry__.build() first")
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(obj, os.path.join(tmp, "k.o"))
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "k.o"], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+        cos = [f for f in os.listdir(tmp) if "gfx950" in f]
+        assert cos, "no gfx950 code object in %s" % obj
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, cos[0])], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        blk = ".agpr_count:" + blk
+        get = lambda key: re.search(r"\." + key + r":\s*(\S+)", blk).group(1)
+        name = get("name")
+        m = re.match(r"_Z23pt_render_simple_kernelILi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])EEv", name)
+        if m:
+            key = ("line", int(m.group(1)), m.group(2) == "1", m.group(3) == "1", int(m.group(4)), m.group(5) == "1")
+        else:
+            m = re.match(r"_Z16pt_render_kernelILi(\d+)ELb([01])ELb([01])ELi(\d+)EEv", name)
+            if not m:
+                continue
+            key = ("interp", int(m.group(1)), m.group(2) == "1", m.group(3) == "1", int(m.group(4)), False)
+        out[key] = {"vgpr": int(get("vgpr_count")), "agpr": int(get("agpr_count")), "spill": int(get("vgpr_spill_count")), "scratch": int(get("private_segment_fixed_size"))}
+    return out
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+def test_every_instantiation_fits_the_registers_of_its_wave_count(mode):
+    ks = kernels_of(mode)
+    assert ks
+    for key, r in ks.items():
+        kind, _, _, _, var, _ = key
+        waves = var if kind == "line" else 3  # the interpreter's variants are all compiled for 3 waves per SIMD
+        assert r["vgpr"] + r["agpr"] <= BUDGET[waves], (key, r)
+
+
+# (kind, mode, counting, textured, waves / variant, chain) -> ceiling on spilled vector registers; the plain (non-counting) instantiations the
+# measured workloads run
+CEILINGS = {
+    ("line", 3, False, False, 6, False): 40,    # the headline: big-scene flat_scene, 6 waves (35)
+    ("line", 3, False, False, 4, False): 0,     # ... and what PORTRAYER_WAVES=4 runs: no scratch at all
+    ("line", 6, False, False, 6, False): 38,    # big-scene, the crate's default semantics (33)
+    ("line", 7, False, False, 5, False): 62,    # big-scene, k-d semantics (56)
+    ("line", 7, False, False, 4, False): 12,    # (10)
+    ("line", 1, False, False, 5, False): 63,    # big-soup / big-mesh (57)
+    ("line", 1, False, False, 4, False): 10,    # macho-cows (7)
+    ("line", 1, False, False, 4, True): 36,     # the mirror scene's chain kernel (32)
+    ("interp", 4, False, True, 1, False): 104,  # transmission-refraction: textured interpreter, maps applied before the state machine (94; 108 with 8 of them in the loop before)
+    ("interp", 4, False, False, 1, False): 20,  # ... untextured (16)
+    ("interp", 5, False, True, 1, False): 16,   # the same scene in the hierarchical semantics (12)
+}
+
+
+def test_spilled_registers_of_the_measured_instantiations_stay_where_they_were():
+    cache = {}
+    for key, ceiling in CEILINGS.items():
+        mode = key[1]
+        if mode not in cache:
+            cache[mode] = kernels_of(mode)
+        assert key in cache[mode], key
+        assert cache[mode][key]["spill"] <= ceiling, (key, cache[mode][key], ceiling)
+    assert cache[3][("line", 3, False, False, 4, False)]["scratch"] == 0
