@@ -1101,6 +1101,13 @@ PT_HD float pt_max3_zero_raw(float a, float b) {  // max(a, b, 0)
     return fmaxf(fmaxf(a, b), 0.0f);
 #endif
 }
+PT_HD float pt_max3_raw(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_PK_ASM)
+    float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+    return fmaxf(fmaxf(a, b), c);
+#endif
+}
 PT_HD float pt_min3_raw(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_PK_ASM)
     float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
@@ -1112,21 +1119,29 @@ PT_HD float pt_min3_raw(float a, float b, float c) {
 // Out: masks of the lanes whose rays reach child 0 / child 1, and of those that reach child 1 strictly before child 0.
 // OCT (see pt_raypk): with wave-uniform signs the entering value of an axis is the lower planes' (bit clear) or the upper planes'
 // (bit set) - known at compile time, 6 packed fmas + 8 min / max + 3 compares; PT_OCT_MIXED: min / max of the two per lane (+ 12).
-template <int OCT>
-PT_HD void pt_slab_pk2(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned long long* m0, unsigned long long* m1, unsigned long long* one_first) {
+// NEAR: the lane's segment starts at t0 > 0 (the k-d semantics' nested mesh walks: a leaf's range [start, end)) - the entering value is
+// clamped there instead of at 0, the same instruction with a register in place of the constant.
+template <int OCT, bool NEAR = false>
+PT_HD void pt_slab_pk2(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned long long* m0, unsigned long long* m1, unsigned long long* one_first, float t0 = 0.0f) {
     const pt_f32x2 ax = pt_pk_fma_bcast(pt_pair_f32(v[0], v[1]), q.a[0]), ay = pt_pk_fma_bcast(pt_pair_f32(v[2], v[3]), q.a[1]), az = pt_pk_fma_bcast(pt_pair_f32(v[4], v[5]), q.a[2]);
     const pt_f32x2 bx = pt_pk_fma_bcast(pt_pair_f32(v[6], v[7]), q.b[0]), by = pt_pk_fma_bcast(pt_pair_f32(v[8], v[9]), q.b[1]), bz = pt_pk_fma_bcast(pt_pair_f32(v[10], v[11]), q.b[2]);
     float tn0, tn1, tf0, tf1;
     if (OCT == PT_OCT_MIXED) {
-        tn0 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x));
-        tn1 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y));
+        if (NEAR) {
+            tn0 = pt_max3_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x), t0);
+            tn1 = pt_max3_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y), t0);
+        } else {
+            tn0 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x));
+            tn1 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y));
+        }
         tf0 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.x, bx.x), pt_max2_raw(ay.x, by.x)), pt_max2_raw(az.x, bz.x), tm);
         tf1 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.y, bx.y), pt_max2_raw(ay.y, by.y)), pt_max2_raw(az.y, bz.y), tm);
     } else {
         const pt_f32x2 ex = (OCT & 1) ? bx : ax, lx = (OCT & 1) ? ax : bx;  // entering / leaving values per axis, both children
         const pt_f32x2 ey = (OCT & 2) ? by : ay, ly = (OCT & 2) ? ay : by;
         const pt_f32x2 ez = (OCT & 4) ? bz : az, lz = (OCT & 4) ? az : bz;
-        tn0 = pt_max3_zero_raw(pt_max2_raw(ex.x, ey.x), ez.x); tn1 = pt_max3_zero_raw(pt_max2_raw(ex.y, ey.y), ez.y);
+        if (NEAR) { tn0 = pt_max3_raw(pt_max2_raw(ex.x, ey.x), ez.x, t0); tn1 = pt_max3_raw(pt_max2_raw(ex.y, ey.y), ez.y, t0); }
+        else { tn0 = pt_max3_zero_raw(pt_max2_raw(ex.x, ey.x), ez.x); tn1 = pt_max3_zero_raw(pt_max2_raw(ex.y, ey.y), ez.y); }
         tf0 = pt_min3_raw(pt_min2_raw(lx.x, ly.x), lz.x, tm); tf1 = pt_min3_raw(pt_min2_raw(lx.y, ly.y), lz.y, tm);
     }
     *m0 = PT_FCMP_LE(tn0, tf0);
@@ -1292,15 +1307,15 @@ PT_HD void pt_descend(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned
 
 // The same inside the two-level walk of scenes with mesh instances: PT_REF_POP when neither child is reached (the caller pops: a
 // marker may end a mesh instance), PT_REF_EMPTY when the stack overflowed.
-template <bool STATS, int OCT>
+template <bool STATS, int OCT, bool NEAR = false>
 PT_HD void pt_descend_mesh(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned long long lanes, bool counts, uint32_t& cur, int& sp, uint32_t* wstack, int words,
-                           PtCounters* cnt) {
+                           PtCounters* cnt, float t0 = 0.0f) {
     while (!(cur & PT_REF_LEAF)) {
         const pt_u32x16 v = pt_sload_node(bvh, cur);
         PT_WAVE_COUNT(4);
         if (STATS && counts) cnt->n_inner++;
         unsigned long long m0, m1, one_first;
-        pt_slab_pk2<OCT>(v, q, tm, &m0, &m1, &one_first);
+        pt_slab_pk2<OCT, NEAR>(v, q, tm, &m0, &m1, &one_first, t0);
         uint32_t near, far;
         const uint32_t code = pt_step_decide(&m0, &m1, one_first, lanes, v[12], v[13], &near, &far);
         uint32_t next = near;
@@ -1724,12 +1739,20 @@ PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_
                                    uint32_t* wstack, int words, PtCounters* cnt) {
     const PtRayPk q = pt_raypk(local);
     float tm = pt_tmax32(lb.t);
+    // the lane's range starts at `start` (the k-d leaf's): boxes that end before it hold no hit of this leaf - a mesh that spans several k-d leaves
+    // is walked once per leaf, each time only where the leaf's range reaches (round 4). Rounded down like the k-d walk's own segment culls.
+#ifdef PT_KD_MESH_NO_NEAR
+    const float t0 = 0.0f;
+#else
+    float t0 = (float)start;
+    t0 = t0 - fabsf(t0) * 2.4e-7f;
+#endif
     unsigned long long pmask = PT_BALLOT(part);
     uint32_t cur = root;
     int sp = 0;
     uint32_t steps = 0;  // (watchdog, as in pt_trace_packet_kd: leaves visited)
     for (;;) {
-        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt);
+        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, PT_OCT_MIXED, true>(sc.bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt, t0);
         steps++;
         if (cur == PT_REF_EMPTY || steps > PT_KD_WALK_STEPS_MAX) return false;
         if (cur != PT_REF_POP) {
