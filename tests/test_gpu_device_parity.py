@@ -97,8 +97,9 @@ def libm(op, a, b):
 def test_device_atan2_acos_against_glibc(ctx):
     """The other libm calls on the device: sphere texture coordinates (sphere.rs:57-60, pt_apply_maps) go through atan2 and
     acos. Their results only select a texel, so a last-bit difference matters only on a texel boundary; the measured bound
-    against glibc itself (pt_test_libm_host) is written here so that a device-library change shows. (glibc 2.35's atan2 still falls back
-    to multi-precision arithmetic - about 1,400 instructions plus the mpa routines in this image's libm - and was not restated like pow.)"""
+    against glibc itself (pt_test_libm_host) is written here so that a device-library change shows. (glibc 2.35's atan2 - about 1,400
+    instructions in this image's stripped libm - was not restated like pow, and it is not correctly rounded either - 0.1 % of its results are not the
+    nearest double, profiles/tools/glibc_atan2_rounding.py -, so a correctly rounded device routine would not equal it.)"""
     rng = np.random.default_rng(5)
     n = 200000
     d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]  # points on the unit sphere, like hit points
