@@ -473,8 +473,8 @@ struct PtMapsOut {
 #else
 #define PT_MAPS_ATTR PT_NOINLINE
 #endif
-PT_MAPS_ATTR PtMapsOut pt_apply_maps(const PtTexView* view, uint32_t mat, uint32_t type, uint32_t sub, double ox, double oy, double oz, double dx, double dy,
-                                    double dz, double px, double py, double pz, double nx, double ny, double nz) {
+PT_HD PtMapsOut pt_apply_maps_body(const PtTexView* view, uint32_t mat, uint32_t type, uint32_t sub, double ox, double oy, double oz, double dx, double dy,
+                                   double dz, double px, double py, double pz, double nx, double ny, double nz) {
     const PtTexInfo* tex = view->tex;
     const uint8_t* tex_rgb = view->tex_rgb;
     const double* uv_trans9 = view->uv_trans + 9 * (size_t)mat;
@@ -549,6 +549,16 @@ PT_MAPS_ATTR PtMapsOut pt_apply_maps(const PtTexView* view, uint32_t mat, uint32
     }
     return out;
 }
+PT_MAPS_ATTR PtMapsOut pt_apply_maps(const PtTexView* view, uint32_t mat, uint32_t type, uint32_t sub, double ox, double oy, double oz, double dx, double dy,
+                                    double dz, double px, double py, double pz, double nx, double ny, double nz) {
+    return pt_apply_maps_body(view, mat, type, sub, ox, oy, oz, dx, dy, dz, px, py, pz, nx, ny, nz);
+}
+// what pt_lane_maps (the interpreter's map stage in front of its state machine) calls: the out-of-line routine, or the body in place (PT_LANE_MAPS_INLINE)
+#if defined(PT_LANE_MAPS_INLINE) || defined(PT_MAPS_INLINE)
+#define PT_LANE_APPLY_MAPS pt_apply_maps_body
+#else
+#define PT_LANE_APPLY_MAPS pt_apply_maps
+#endif
 
 // flat_scene.rs:85-95 / scene.rs:100-112 + material.rs:109-144 for the winning candidate of a ray: the model-space hit is rebuilt
 // with the reference's expressions, point and normal go to world space (HIER: level by level), the material's maps are applied.
@@ -697,7 +707,7 @@ PT_HD uint32_t pt_lane_maps(const PtSceneView& sc, const PtRay& ray, const PtHit
     PtRay local;
     PtVec3 p, n;
     pt_hit_model<HIER>(sc, ray, hit, &type, &mat, &local, &p, &n);
-    PtMapsOut mo = pt_apply_maps(sc.texview, mat, type, hit.sub, local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z, p.x, p.y, p.z, n.x, n.y, n.z);
+    PtMapsOut mo = PT_LANE_APPLY_MAPS(sc.texview, mat, type, hit.sub, local.o.x, local.o.y, local.o.z, local.d.x, local.d.y, local.d.z, p.x, p.y, p.z, n.x, n.y, n.z);
     if (mo.has_n) fr.set_l3(PT_L_N, pt_v3(mo.n[0], mo.n[1], mo.n[2]));
     return PT_PRE_MAPS | (mo.has_n ? PT_PRE_NORMAL : 0u) | mo.texel;
 }
