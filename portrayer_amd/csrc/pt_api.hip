@@ -1071,10 +1071,10 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // Scenes whose hits spawn rays need the interpreter kernel (3 waves per SIMD); the others run the straight-line kernel at 3 or
     // 4 waves per SIMD. PORTRAYER_INTERP=1 (builds with -DPT_KEEP_INTERP): the interpreter on those too, for A/B runs.
     const bool kd_sem = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH || a.scene.mode == PT_MODE_KD_MESH;
-    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex) || c->four_waves_hier)) ? (c->five_waves ? PT_LINE_TOP_WAVES : ((c->five_waves_mesh && !tex) ? 5 : 4)) : 0;
+    a.four_waves = (!c->spawns && (c->four_waves || (c->four_waves_untextured && !tex) || c->four_waves_hier)) ? (c->five_waves ? PT_LINE_TOP_WAVES : ((c->five_waves_mesh && !tex) ? PT_MESH_TOP_WAVES : 4)) : 0;
     if (const char* e = getenv("PORTRAYER_WAVES")) {
         const int wv = atoi(e);
-        a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? PT_LINE_TOP_WAVES : ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_HIER_MESH)) ? 5 : 4)) : 0;
+        a.four_waves = (!c->spawns && wv >= 4) ? ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT_NOMESH || a.scene.mode == PT_MODE_HIER_NOMESH)) ? PT_LINE_TOP_WAVES : ((wv >= 5 && (a.scene.mode == PT_MODE_FLAT || a.scene.mode == PT_MODE_HIER_MESH)) ? PT_MESH_TOP_WAVES : 4)) : 0;
     }
     if (kd_sem) {
         // The k-d semantics: mesh-free scenes with many nodes take the 4-wave straight-line kernel too (big-scene 35.7 -> 30.7 ms: the per-lane

@@ -357,7 +357,7 @@ static hipError_t pt_launch_variant(const PtRenderArgs& a, int variant, bool kd_
     case PT_RUN_LINE5:  // mesh-free scenes in the flat_scene / hierarchical semantics: 96 registers, 5 waves per SIMD
         if constexpr (MODE == PT_MODE_FLAT_NOMESH || MODE == PT_MODE_HIER_NOMESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, PT_LINE_TOP_WAVES>>(lds, a, n_cu, stream, grid_out, launch);
         if constexpr (MODE == PT_MODE_KD_NOMESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 5>>(lds, a, n_cu, stream, grid_out, launch);  // (its saved range bounds want the LDS rows: 5 at most)
-        if constexpr (MODE == PT_MODE_FLAT || MODE == PT_MODE_HIER_MESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 5>>(lds, a, n_cu, stream, grid_out, launch);  // scenes of very many triangles: their walks wait for node fetches
+        if constexpr (MODE == PT_MODE_FLAT || MODE == PT_MODE_HIER_MESH) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, PT_MESH_TOP_WAVES>>(lds, a, n_cu, stream, grid_out, launch);  // scenes of very many triangles: their walks wait for node fetches
         [[fallthrough]];
     case PT_RUN_LINE4:  // the k-d tree semantics with mesh instances (per-lane walk through two levels of trees) have no 4-wave instantiation
         if constexpr (MODE != PT_MODE_KD) return pt_launch_kernel<&pt_render_simple_kernel<MODE, STATS, TEX, 4>>(lds, a, n_cu, stream, grid_out, launch);

@@ -127,6 +127,9 @@ enum { PT_RUN_INTERP = 0, PT_RUN_INTERP_PARK = 1, PT_RUN_LINE4 = 2, PT_RUN_LINE3
 // it because that build hung: section 2). -DPT_LINE_TOP_WAVES=5 builds round 3's.
 #define PT_LINE_TOP_WAVES 6
 #endif
+#ifndef PT_MESH_TOP_WAVES
+#define PT_MESH_TOP_WAVES 5   // ... and of scenes of very many triangles in plain Mesh instances (6 measured: profiles/r04/notes.md section 7)
+#endif
 struct PtRenderArgs {
     PtSceneView scene;
     PtCamera cam;
