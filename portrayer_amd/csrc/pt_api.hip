@@ -85,6 +85,24 @@ __global__ void __launch_bounds__(256) pt_copy1_kernel(const double2* __restrict
 // 3.32 against 3.72 node visits per ray). PORTRAYER_COLLAPSE=plain | mesh | area.
 // One thread per two-child node; entries of the array that no tree uses (the device build reserves n - 1 nodes per mesh
 // and may need fewer) hold garbage, are never referenced, and are only kept from reading out of bounds.
+// tri_leaf: the edge record of every triangle named by a slot of the items array, in slot order (80 bytes a slot: 9 f64 + the triangle's index), so
+// that a mesh leaf's triangles lie side by side and the wave-uniform walks fetch them without going through bvh_items first.
+__global__ void __launch_bounds__(256) pt_tri_leaf_kernel(const uint32_t* __restrict__ items, uint32_t n_items, const double* __restrict__ tri_e, uint32_t n_tris,
+                                                         double* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_items) return;
+    const uint32_t t = items[i];
+    double* o = out + 10 * (size_t)i;
+    if (t < n_tris) {
+        const double* e = tri_e + 9 * (size_t)t;
+        for (int k = 0; k < 9; k++) o[k] = e[k];
+    } else {
+        for (int k = 0; k < 9; k++) o[k] = 0.0;
+    }
+    union { double d; uint32_t u[2]; } c; c.u[0] = t; c.u[1] = 0u;
+    o[9] = c.d;
+}
+
 __global__ void __launch_bounds__(256) pt_collapse4_kernel(const PtBvhNode* __restrict__ bvh2, PtBvh4Node* __restrict__ bvh4, uint32_t n, int by_area_mode,
                                                             uint32_t scene_first, uint32_t scene_end) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,7 +223,7 @@ struct pt_context {
     int device = 0;
     int n_cu = 0;
     std::string err;
-    PtBuf inv, fwd, nrm, info, tri_v, tri_e, tri_n, meshes, materials, lights, bvh, bvh4, bvh_items, kd, kd_items;
+    PtBuf inv, fwd, nrm, info, tri_v, tri_e, tri_leaf, tri_n, meshes, materials, lights, bvh, bvh4, bvh_items, kd, kd_items;
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, texview, mkd, mkd_items;
     PtBuf node_box, kd_box, mkd_box, mkd_item_box, kd_ref;
     PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank, hier_rec;  // PT_TRAVERSE_HIER: the scene graph
@@ -301,7 +319,7 @@ extern "C" int pt_context_create(int device, pt_context** out) {
 extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_e, &c->tri_n, &c->meshes, &c->materials, &c->lights,
+    PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_e, &c->tri_leaf, &c->tri_n, &c->meshes, &c->materials, &c->lights,
                      &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->kd_ref, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank, &c->hier_rec};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& sl : c->slot) {
@@ -759,6 +777,14 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
             PT_HIP(c, hipDeviceSynchronize());
         }
         lap("four-child form");
+        if ((rc = pt_reserve(c, c->tri_leaf, std::max<size_t>(n_items, 1) * 80))) return rc;
+        if (n_items && total_tris) {
+            hipLaunchKernelGGL(pt_tri_leaf_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, nullptr, (const uint32_t*)c->bvh_items.p, (uint32_t)n_items, (const double*)c->tri_e.p,
+                               (uint32_t)total_tris, (double*)c->tri_leaf.p);
+            PT_HIP(c, hipGetLastError());
+            PT_HIP(c, hipDeviceSynchronize());
+        }
+        lap("triangle records in leaf order");
     }
     for (size_t i = 0; i < kdn.size() && !kd_box32.empty(); i++) for (int r = 0; r < 6; r++) kdn[i].box[r] = kd_box32[6 * i + r];
     for (size_t i = 0; i < mkd.size() && !mkd_box.empty(); i++) for (int r = 0; r < 6; r++) mkd[i].box[r] = mkd_box[6 * i + r];
@@ -885,7 +911,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     memset(&v, 0, sizeof v);
     v.n_nodes = n; v.n_lights = s->n_lights;
     v.inv = (const double*)c->inv.p; v.fwd = (const double*)c->fwd.p; v.nrm = (const double*)c->nrm.p;
-    v.info = (const uint32_t*)c->info.p; v.tri_v = (const double*)c->tri_v.p; v.tri_e = (const double*)c->tri_e.p; v.tri_n = (const double*)c->tri_n.p;
+    v.info = (const uint32_t*)c->info.p; v.tri_v = (const double*)c->tri_v.p; v.tri_e = (const double*)c->tri_e.p; v.tri_leaf = (const double*)c->tri_leaf.p; v.tri_n = (const double*)c->tri_n.p;
     v.meshes = (const PtMeshInfo*)c->meshes.p; v.materials = (const double*)c->materials.p; v.lights = (const double*)c->lights.p;
     for (int k = 0; k < 3; k++) v.ambient[k] = s->ambient[k];
     v.bvh = (const PtBvhNode*)c->bvh.p; v.bvh4 = (const PtBvh4Node*)c->bvh4.p; v.bvh_items = (const uint32_t*)c->bvh_items.p;

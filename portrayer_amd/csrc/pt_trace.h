@@ -1033,6 +1033,10 @@ PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, cons
 // bit a set: they all enter slabs of axis a through the UPPER plane (negative direction), clear: through the lower one; PT_OCT_MIXED
 // when some axis has rays of both signs among those lanes. Rays through one pixel, or from neighbouring points to one light,
 // nearly always share their signs, and then the tree step needs no min / max to tell entering from leaving (pt_slab_pk2).
+// Slot `slot` of a mesh leaf (wave-uniform): the triangle's record into scalar registers (dwords 0..15 in `a`, 16 / 17 in b0 / b1), its index returned.
+// Default: the record comes from tri_leaf, laid out in slot order - ONE fetch, and a leaf's second triangle sits in the line(s) the first one brought in;
+// -DPT_TRI_VIA_ITEMS (and the corner form, -DPT_NO_TRI_EDGES): the slot's index from bvh_items first, then the record it names (two dependent fetches).
+PT_HD uint32_t pt_load_leaf_triangle(const PtSceneView& sc, uint32_t slot, pt_u32x16& a, uint32_t& b0, uint32_t& b1);
 #ifdef PT_NO_TRI_EDGES  // A/B: the wave-uniform walks test triangles from their corners again
 #define PT_TRI_REC(sc) (sc).tri_v
 #define PT_TRI_HIT pt_triangle_hit
@@ -1040,6 +1044,34 @@ PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, cons
 #define PT_TRI_REC(sc) (sc).tri_e
 #define PT_TRI_HIT pt_triangle_hit_e
 #endif
+PT_HD uint32_t pt_load_leaf_triangle(const PtSceneView& sc, uint32_t slot, pt_u32x16& a, uint32_t& b0, uint32_t& b1) {
+#if defined(PT_TRI_VIA_ITEMS) || defined(PT_NO_TRI_EDGES)
+    const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[slot]);
+    const double* rec = PT_TRI_REC(sc) + 9 * (size_t)tri;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 b;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(rec)) : "memory");
+    b0 = b[0]; b1 = b[1];
+#else
+    a = *reinterpret_cast<const pt_u32x16*>(rec);
+    b0 = reinterpret_cast<const uint32_t*>(rec)[16]; b1 = reinterpret_cast<const uint32_t*>(rec)[17];
+#endif
+    return tri;
+#else
+    const double* rec = sc.tri_leaf + 10 * (size_t)slot;
+#if defined(__HIP_DEVICE_COMPILE__)
+    pt_u32x4 b;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(rec)) : "memory");
+    b0 = b[0]; b1 = b[1];
+    return b[2];
+#else
+    a = *reinterpret_cast<const pt_u32x16*>(rec);
+    b0 = reinterpret_cast<const uint32_t*>(rec)[16]; b1 = reinterpret_cast<const uint32_t*>(rec)[17];
+    return reinterpret_cast<const uint32_t*>(rec)[18];
+#endif
+#endif
+}
 #define PT_OCT_MIXED 8
 PT_HD PtRayPk pt_raypk(const PtRay& r, bool lanes, int* oct) {
     PtRayPk q;
@@ -1476,21 +1508,9 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
             if (inst != PT_NO_HIT) {  // triangles of the mesh being walked
                 PT_CYC_BEGIN();
                 for (uint32_t i = 0; i < count; i++) {
-                    const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[first + i]);
-                    const double* rec = PT_TRI_REC(sc) + 9 * (size_t)tri;
                     pt_u32x16 a;
                     uint32_t b0, b1;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    {
-                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                        u32x2 b;
-                        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(rec)) : "memory");
-                        b0 = b[0]; b1 = b[1];
-                    }
-#else
-                    a = *reinterpret_cast<const pt_u32x16*>(rec);
-                    b0 = reinterpret_cast<const uint32_t*>(rec)[16]; b1 = reinterpret_cast<const uint32_t*>(rec)[17];
-#endif
+                    const uint32_t tri = pt_load_leaf_triangle(sc, first + i, a, b0, b1);
                     double tv[9];
 #pragma unroll
                     for (int k = 0; k < 8; k++) tv[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
@@ -1759,21 +1779,9 @@ PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_
             const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
             if (STATS && part) cnt->n_leaf++;
             for (uint32_t i = 0; i < count; i++) {
-                const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[first + i]);
-                const double* rec = PT_TRI_REC(sc) + 9 * (size_t)tri;
                 pt_u32x16 a;
                 uint32_t b0, b1;
-#if defined(__HIP_DEVICE_COMPILE__)
-                {
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    u32x2 b;
-                    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(rec)) : "memory");
-                    b0 = b[0]; b1 = b[1];
-                }
-#else
-                a = *reinterpret_cast<const pt_u32x16*>(rec);
-                b0 = reinterpret_cast<const uint32_t*>(rec)[16]; b1 = reinterpret_cast<const uint32_t*>(rec)[17];
-#endif
+                const uint32_t tri = pt_load_leaf_triangle(sc, first + i, a, b0, b1);
                 double tv[9];
 #pragma unroll
                 for (int k = 0; k < 8; k++) tv[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
