@@ -73,6 +73,9 @@ struct PtMeshInfo {
     double kd_bbox_inv[12];  // BoundingBox::invtrans of the root bounds (kdmesh.rs:66-68)
 };
 
+static_assert(offsetof(PtMeshInfo, tri_first) == 96 && offsetof(PtMeshInfo, blas_root) == 104 && offsetof(PtMeshInfo, kd_root) == 108,
+              "pt_sload_mat12_x4 (pt_trace.h) reads {tri_first, tri_count, blas_root, kd_root} as the 16 bytes behind bbox_inv");
+
 struct PtTexInfo {  // one RgbImageBuffer (texture.rs:74-76) inside tex_rgb
     uint64_t offset;
     uint32_t width, height;

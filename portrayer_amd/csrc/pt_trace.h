@@ -956,6 +956,22 @@ PT_HD void pt_sload_mat12(const double* p, double m[12]) {
 #pragma unroll
     for (int k = 0; k < 4; k++) m[8 + k] = pt_f64_of(b[2 * k], b[2 * k + 1]);
 }
+// ... and the 16 bytes that follow the 96 (PtMeshInfo: the box inverse, then {tri_first, tri_count, blas_root, kd_root}), in the same round trip
+PT_HD void pt_sload_mat12_x4(const double* p, double m[12], pt_u32x4& tail) {
+    pt_u32x16 a;
+    pt_u32x8 b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b), "=&s"(tail) : "s"(pt_uniform_ptr(p)) : "memory");
+#else
+    a = *reinterpret_cast<const pt_u32x16*>(p);
+    b = *reinterpret_cast<const pt_u32x8*>(reinterpret_cast<const char*>(p) + 64);
+    tail = *reinterpret_cast<const pt_u32x4*>(reinterpret_cast<const char*>(p) + 96);
+#endif
+#pragma unroll
+    for (int k = 0; k < 8; k++) m[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) m[8 + k] = pt_f64_of(b[2 * k], b[2 * k + 1]);
+}
 // May a level whose matrices are the identity be skipped for this ray? ((1 x + 0 y) + 0 z) + 0 is x bit for bit unless x is -0 (which
 // the additions turn into +0) or something is not finite (0 times infinity). Wave-uniform: true when no lane's ray has such a component.
 PT_HD bool pt_ray_identity_safe(const PtRay& r, bool has_ray) {
@@ -1530,9 +1546,12 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                 bool entered = false;
                 for (uint32_t i = 0; i < count && !entered; i++) {
                     const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
-                    const uint32_t type = PT_UNIFORM_U32(sc.info[4 * (size_t)node]);
+                    // (fetches that depend on each other cost a round trip through the scalar cache each - a mesh instance is entered with three: the
+                    // node's {type, data, ..}, its inverse, the mesh record's {box inverse, roots} - not with one per field: round 4, c47)
+                    const pt_u32x4 info4 = pt_sload4(sc.info + 4 * (size_t)node);
+                    const uint32_t type = info4[0];
                     if (type == PT_MESH || type == PT_KDMESH) {
-                        const uint32_t data = PT_UNIFORM_U32(sc.info[4 * (size_t)node + 1]);
+                        const uint32_t data = info4[1];
                         const PtMeshInfo* mi = sc.meshes + data;
                         PtRay lr;
                         if (HIER) {
@@ -1543,7 +1562,10 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                             lr = pt_ray_to_local(m, ray);
                         }
                         if (STATS && alive) cnt->n_analytic++;
-                        if (KDMESH && type == PT_KDMESH && (int32_t)PT_UNIFORM_U32((uint32_t)mi->kd_root) >= 0) {  // the reference's own triangle tree (quirk Q3)
+                        double bi[12];
+                        pt_u32x4 head;  // {tri_first, tri_count, blas_root, kd_root}
+                        pt_sload_mat12_x4(mi->bbox_inv, bi, head);
+                        if (KDMESH && type == PT_KDMESH && (int32_t)head[3] >= 0) {  // the reference's own triangle tree (quirk Q3)
                             if (alive) {
                                 double t; uint32_t tri = 0;
                                 if (pt_kdmesh_hit<STATS>(sc, *mi, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, 0), lane_stk, 0, &t, &tri, cnt)) {
@@ -1555,11 +1577,9 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                             continue;
                         }
                         // mesh.rs:146-155: box test, then the triangles (also a KDMesh without a tree of its own: PORTRAYER_KDMESH_AS_MESH)
-                        const uint32_t root = PT_UNIFORM_U32(mi->blas_root);
+                        const uint32_t root = head[2];
                         if (STATS && alive) cnt->n_bbox++;
                         if (root == PT_REF_EMPTY) continue;
-                        double bi[12];
-                        pt_sload_mat12(mi->bbox_inv, bi);
                         const bool inside = alive && pt_bbox_test_hit(bi, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, 0));
                         const unsigned long long inside_mask = PT_BALLOT(inside);
                         if (!inside_mask) continue;
@@ -1979,17 +1999,18 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                     bool hit = false;
                     if (MESH && (type == PT_MESH || type == PT_KDMESH)) {
                         const PtMeshInfo* mi = sc.meshes + data;
-                        if (KDMESH && type == PT_KDMESH && (int32_t)PT_UNIFORM_U32((uint32_t)mi->kd_root) >= 0) {  // the reference's own triangle tree (quirk Q3), per lane
+                        double bi[12];
+                        pt_u32x4 head;  // {tri_first, tri_count, blas_root, kd_root}: one round trip with the box inverse
+                        pt_sload_mat12_x4(mi->bbox_inv, bi, head);
+                        if (KDMESH && type == PT_KDMESH && (int32_t)head[3] >= 0) {  // the reference's own triangle tree (quirk Q3), per lane
                             if (test_l) {
                                 double t; uint32_t tri = 0;
                                 if (pt_kdmesh_hit<STATS>(sc, *mi, local, start, pt_cand_end(lb, item, 0), lane_stk, 0, &t, &tri, cnt)) { lb.t = t; lb.node = item; lb.sub = tri; hit = true; }
                             }
                         } else {  // mesh.rs:146-155: box test, then the triangles (also a KDMesh without a tree of its own: PORTRAYER_KDMESH_AS_MESH)
-                            const uint32_t root = PT_UNIFORM_U32(mi->blas_root);
+                            const uint32_t root = head[2];
                             if (STATS && test_l) cnt->n_bbox++;
                             if (root == PT_REF_EMPTY) continue;
-                            double bi[12];
-                            pt_sload_mat12(mi->bbox_inv, bi);
                             const bool inside = test_l && pt_bbox_test_hit(bi, local, start, pt_cand_end(lb, item, 0));
                             if (!pt_any(inside)) continue;
                             if (!pt_packet_mesh_below_kd<STATS>(sc, item, root, local, inside, start, PT_LANES(any_m), lb, hit, wstack + sp, wwords - sp, cnt)) failed = true;

@@ -66,7 +66,7 @@ CEILINGS = {
     ("line", 7, False, False, 4, False): 12,    # (10)
     ("line", 1, False, False, 5, False): 63,    # big-soup / big-mesh (57)
     ("line", 1, False, False, 4, False): 10,    # macho-cows (7)
-    ("line", 1, False, False, 4, True): 36,     # the mirror scene's chain kernel (32)
+    ("line", 1, False, False, 4, True): 42,     # the mirror scene's chain kernel (38)
     ("interp", 4, False, True, 1, False): 104,  # transmission-refraction: textured interpreter, maps applied before the state machine (94; 108 with 8 of them in the loop before)
     ("interp", 4, False, False, 1, False): 20,  # ... untextured (16)
     ("interp", 5, False, True, 1, False): 16,   # the same scene in the hierarchical semantics (12)
