@@ -184,8 +184,6 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
     if (STATS) memset(&cnt, 0, sizeof cnt);
     unsigned q_next = 0, q_end = 0, q_seen = 0;  // the wavefront's private batch of items (wave-uniform), as in pt_render_kernel
     if (a.fine_queues) q_next = blockIdx.x % a.fine_queues;
-    unsigned ticket = 0;       // lane 0: the position drawn from queue q_next for the NEXT item (fine queues)
-    bool have_ticket = false;  // wave-uniform
 
     for (;;) {
         unsigned w;
@@ -203,26 +201,6 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
             if (q >= a.n_items) break;
             w = a.item_stride == 1u ? q : (unsigned)(((unsigned long long)q * a.item_stride) % a.n_items);
         } else {  // one item at a time from interleaved queues
-#ifndef PT_NO_TICKET_AHEAD
-            // The ticket for THIS item was drawn while the previous one was being rendered (`ticket`, lane 0): the atomic's round trip to the L2 - a
-            // microsecond in which the wavefront would stand still, once per item - is hidden behind the item's work. A wavefront therefore
-            // always holds one ticket it has not used yet; the last one of each wavefront lies beyond the queue's end and is dropped.
-            for (;;) {
-                if (!have_ticket) { if (lane == 0) ticket = atomicAdd(a.work_queues + q_next * PT_QUEUE_STRIDE, 1u); }
-                const unsigned idx = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-                have_ticket = false;
-                const unsigned long long pos = (unsigned long long)idx * a.fine_queues + q_next;
-                if (pos < a.n_items) {
-                    w = (unsigned)pos; q_end = 0;
-                    if (lane == 0) ticket = atomicAdd(a.work_queues + q_next * PT_QUEUE_STRIDE, 1u);  // the next item's, waited for at the top of the next round
-                    have_ticket = true;
-                    break;
-                }
-                q_next = q_next + 1u == a.fine_queues ? 0u : q_next + 1u;
-                if (++q_end == a.fine_queues) { w = 0xFFFFFFFFu; break; }
-            }
-            if (w == 0xFFFFFFFFu) break;
-#else
             for (;;) {
                 unsigned idx = 0;
                 if (lane == 0) idx = atomicAdd(a.work_queues + q_next * PT_QUEUE_STRIDE, 1u);
@@ -233,7 +211,6 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
                 if (++q_end == a.fine_queues) { w = 0xFFFFFFFFu; break; }
             }
             if (w == 0xFFFFFFFFu) break;
-#endif
         }
 
 #ifdef PT_CYCLES  // sections of an item outside the walks: diag[3] primary ray, diag[4] surface of the hit, diag[6] light + shadow ray set-up, diag[7] light term
