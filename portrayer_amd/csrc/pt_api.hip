@@ -226,7 +226,7 @@ struct pt_context {
     PtBuf inv, fwd, nrm, info, tri_v, tri_e, tri_leaf, tri_n, meshes, materials, lights, bvh, bvh4, bvh_items, kd, kd_items;
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, texview, mkd, mkd_items;
     PtBuf node_box, kd_box, mkd_box, mkd_item_box, kd_ref;
-    PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank, hier_rec;  // PT_TRAVERSE_HIER: the scene graph
+    PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank, hier_rec, own_inv;  // PT_TRAVERSE_HIER: the scene graph
     PtBuf spill, stack_spill, accum, bg, rgb, linear, misc;  // misc: work counter + overflow flag (8 B), PtCounters at +256
     bool needs_spill = false;  // some material is reflective (recursion frames) or the scene has more than 32 lights
     bool spawns = false;       // some material is reflective: hits spawn rays, so the cost of a pixel varies by orders of magnitude
@@ -320,7 +320,7 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_e, &c->tri_leaf, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->kd_ref, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank, &c->hier_rec};
+                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->kd_ref, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank, &c->hier_rec, &c->own_inv};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& sl : c->slot) {
         if (sl.ev0) hipEventDestroy(sl.ev0);
@@ -549,6 +549,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     std::vector<uint32_t> info(4 * (size_t)n);
     std::vector<double> g_inv, g_fwd, g_nrm;
     std::vector<uint32_t> chain_off, chain, dfs_rank, hier_rec;
+    std::vector<double> own_inv;
     if (traverse == PT_TRAVERSE_HIER && n) {
         const uint32_t g = s->n_graph_nodes;
         g_inv.resize(12 * (size_t)g); g_fwd.resize(12 * (size_t)g); g_nrm.resize(9 * (size_t)g);
@@ -578,9 +579,11 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         std::vector<uint8_t> g_ident(g);
         for (uint32_t i = 0; i < g; i++) g_ident[i] = identity(i) ? 1 : 0;
         hier_rec.assign(8 * (size_t)n, 0u);
+        own_inv.assign(12 * (size_t)n, 0.0);
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t len = chain_off[i + 1] - chain_off[i];
             uint32_t* rec = &hier_rec[8 * (size_t)i];
+            for (int r = 0; r < 12; r++) own_inv[12 * (size_t)i + r] = g_inv[12 * (size_t)chain[chain_off[i + 1] - 1] + r];  // the node's own level: the last of its path
             if (len > 7) { rec[0] = 255u; continue; }
             rec[0] = len;
             for (uint32_t k = 0; k < len; k++) {
@@ -790,7 +793,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
     for (size_t i = 0; i < mkd.size() && !mkd_box.empty(); i++) for (int r = 0; r < 6; r++) mkd[i].box[r] = mkd_box[6 * i + r];
     if ((rc = pt_upload(c, c->g_inv, g_inv)) || (rc = pt_upload(c, c->g_fwd, g_fwd)) || (rc = pt_upload(c, c->g_nrm, g_nrm)) ||
         (rc = pt_upload(c, c->chain_off, chain_off)) || (rc = pt_upload(c, c->chain, chain)) || (rc = pt_upload(c, c->dfs_rank, dfs_rank)) ||
-        (rc = pt_upload(c, c->hier_rec, hier_rec)))
+        (rc = pt_upload(c, c->hier_rec, hier_rec)) || (rc = pt_upload(c, c->own_inv, own_inv)))
         return rc;
     if ((rc = pt_upload(c, c->inv, inv)) || (rc = pt_upload(c, c->fwd, fwd)) || (rc = pt_upload(c, c->nrm, nrm)) ||
         (rc = pt_upload(c, c->info, info)) || (rc = pt_upload(c, c->tri_n, tri_n)) ||
@@ -935,7 +938,7 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         v.mode = s->n_meshes == 0 ? PT_MODE_HIER_NOMESH : (any_kdmesh ? PT_MODE_HIER : PT_MODE_HIER_MESH);
         v.g_inv = (const double*)c->g_inv.p; v.g_fwd = (const double*)c->g_fwd.p; v.g_nrm = (const double*)c->g_nrm.p;
         v.chain_off = (const uint32_t*)c->chain_off.p; v.chain = (const uint32_t*)c->chain.p; v.dfs_rank = (const uint32_t*)c->dfs_rank.p;
-        v.hier_rec = (const uint32_t*)c->hier_rec.p;
+        v.hier_rec = (const uint32_t*)c->hier_rec.p; v.own_inv = (const double*)c->own_inv.p;
     }
     // a level of the four-child walk pushes up to three pending children; it covers two levels of the two-child tree in the plain
     // collapse and at least one when nodes are opened by area

@@ -101,6 +101,7 @@ struct PtSceneView {
     const uint32_t* info;
     const double* tri_v;
     const double* tri_e;   // n_tris x 9 f64: corner a, a - b, a - c (pt_triangle_hit_e): what the wave-uniform walks test triangles from
+    const double* own_inv;   // hierarchical semantics: per flattened node the inverse of its OWN (last) path level, 12 f64 - what most leaf tests need, fetched with the path record
     const double* tri_leaf;  // one 80-byte record per slot of bvh_items (round 4): the edge record of the triangle the slot names + its index (dword 18) - a mesh leaf's
                              // triangles side by side, without the look-up through bvh_items (slots that name no triangle: zeros)
     const double* tri_n;

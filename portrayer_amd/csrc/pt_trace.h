@@ -1015,8 +1015,39 @@ PT_HD PtRay pt_node_local_ray_rec(const PtSceneView& sc, uint32_t node, const pt
     }
     return r;
 }
+// The same with the node's OWN level's inverse (sc.own_inv, fetched by the caller in the round trip that brought the path record): when every level above the
+// node's own is an identity that may be skipped - every reference scene: primitives under an untransformed root - the own level is all there is to apply, and
+// no second, dependent fetch is needed (round 4: the hierarchical semantics' leaf tests took two round trips where flat_scene's take one).
+PT_HD PtRay pt_node_local_ray_rec_own(const PtSceneView& sc, uint32_t node, const pt_u32x8& rec, const double* own, const PtRay& ray, bool identity_ok) {
+#ifndef PT_HIER_NO_OWN
+    const uint32_t len = rec[0] & 255u;
+    if (identity_ok && len >= 1u && len <= 7u) {
+        const uint32_t above = (1u << (len - 1u)) - 1u;  // the levels before the last
+        if (((rec[0] >> 8) & above) == above) {
+            if ((rec[0] >> (8u + len - 1u)) & 1u) return ray;  // the own level is an identity too
+            return pt_ray_to_local(own, ray);
+        }
+    }
+#endif
+    return pt_node_local_ray_rec(sc, node, rec, ray, identity_ok);
+}
 PT_HD PtRay pt_node_local_ray_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray, bool identity_ok) {
-    return pt_node_local_ray_rec(sc, node, pt_sload8(sc.hier_rec + 8 * (size_t)node), ray, identity_ok);
+    pt_u32x8 rec;
+    double own[12];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_HIER_NO_OWN)
+    pt_u32x16 a;
+    pt_u32x8 b;
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(rec), "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(sc.hier_rec + 8 * (size_t)node)), "s"(pt_uniform_ptr(sc.own_inv + 12 * (size_t)node)) : "memory");
+#pragma unroll
+    for (int k = 0; k < 8; k++) own[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) own[8 + k] = pt_f64_of(b[2 * k], b[2 * k + 1]);
+#else
+    rec = pt_sload8(sc.hier_rec + 8 * (size_t)node);
+    for (int k = 0; k < 12; k++) own[k] = sc.own_inv[12 * (size_t)node + k];
+#endif
+    return pt_node_local_ray_rec_own(sc, node, rec, own, ray, identity_ok);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1258,33 +1289,35 @@ PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRa
     const void* info_ptr = sc.info + 4 * (size_t)node;
     const void* rec = sc.inv + 12 * (size_t)node;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (HIER) {  // ... and the node's path record (hier_rec) instead of a composed inverse
-        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(info), "=&s"(b) : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(sc.hier_rec + 8 * (size_t)node)) : "memory");
+    pt_u32x8 hrec;  // HIER: the node's path record
+    if (HIER) {  // ... the node's path record (hier_rec) and the inverse of its OWN level instead of a composed inverse
+        asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\ts_load_dwordx16 %2, %6, 0x0\n\ts_load_dwordx8 %3, %6, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(info), "=&s"(hrec), "=&s"(a), "=&s"(b)
+                     : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(sc.hier_rec + 8 * (size_t)node)), "s"(pt_uniform_ptr(sc.own_inv + 12 * (size_t)node)) : "memory");
     } else {
         asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(info), "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(rec)) : "memory");
     }
 #else
     info = *static_cast<const pt_u32x4*>(info_ptr);
+    pt_u32x8 hrec;
     if (HIER) {
-        b = *reinterpret_cast<const pt_u32x8*>(sc.hier_rec + 8 * (size_t)node);
-    } else {
-        a = *static_cast<const pt_u32x16*>(rec);
-        b = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(rec) + 64);
+        hrec = *reinterpret_cast<const pt_u32x8*>(sc.hier_rec + 8 * (size_t)node);
+        rec = sc.own_inv + 12 * (size_t)node;
     }
+    a = *static_cast<const pt_u32x16*>(rec);
+    b = *reinterpret_cast<const pt_u32x8*>(static_cast<const char*>(rec) + 64);
 #endif
     const uint32_t type = info[0], data = info[1];
     PtRay local;
-    if (HIER) {
-        local = pt_node_local_ray_rec(sc, node, b, ray, identity_ok);
-    } else {
+    {
         double m[12];
 #pragma unroll
         for (int k = 0; k < 8; k++) m[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
 #pragma unroll
         for (int k = 0; k < 4; k++) m[8 + k] = pt_f64_of(b[2 * k], b[2 * k + 1]);
-        local = pt_ray_to_local(m, ray);
+        if (HIER) local = pt_node_local_ray_rec_own(sc, node, hrec, m, ray, identity_ok);
+        else local = pt_ray_to_local(m, ray);
     }
     if (STATS) cnt->n_analytic++;
     double t;
