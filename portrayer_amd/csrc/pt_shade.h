@@ -565,6 +565,16 @@ PT_MAPS_ATTR PtMapsOut pt_apply_maps(const PtTexView* view, uint32_t mat, uint32
 
 // flat_scene.rs:85-95 / scene.rs:100-112 + material.rs:109-144 for the winning candidate of a ray: the model-space hit is rebuilt
 // with the reference's expressions, point and normal go to world space (HIER: level by level), the material's maps are applied.
+// true when an identity transform leaves every component of v as it is, bit for bit: none is -0 (the sums would make it +0, or keep it, depending on the
+// other components' signs) and none is infinite or NaN (0 x infinity)
+PT_HD bool pt_identity_safe(PtVec3 v) {
+    auto odd = [](double c) {
+        union { double d; uint32_t u[2]; } b; b.d = c;
+        return (b.u[1] == 0x80000000u && b.u[0] == 0u) || (b.u[1] & 0x7FF00000u) == 0x7FF00000u;
+    };
+    return !(odd(v.x) || odd(v.y) || odd(v.z));
+}
+
 // The hit in the node's model space: its point p and raw normal n, the ray there, the node's type and material.
 template <bool HIER>
 PT_HD void pt_hit_model(const PtSceneView& sc, const PtRay& ray, const PtHit& hit, uint32_t* type_out, uint32_t* mat_out, PtRay* local_out, PtVec3* p_out, PtVec3* n_out) {
@@ -596,7 +606,9 @@ PT_HD void pt_hit_model(const PtSceneView& sc, const PtRay& ray, const PtHit& hi
 // MAPS_LATER (the interpreter kernel): a material's texture / normal map is NOT applied here - pt_lane_maps has done it for the
 // lane before the state machine was entered (the map code then sits outside the state machine, where the registers it needs
 // are spilled around it and not around every pass: profiles/r04/notes.md section 6). Returns true when the material has a map.
-template <bool TEX, bool HIER, bool MAPS_LATER = false>
+// SKIP_IDENT: identity levels of a hierarchical path are skipped on the way up (the interpreter kernel: +2 % on the dielectric scenes; the straight-line kernels are
+// as fast or faster applying every level, c51).
+template <bool TEX, bool HIER, bool MAPS_LATER = false, bool SKIP_IDENT = false>
 PT_HD bool pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& hit, PtVec3* P_out, PtVec3* N_out, uint32_t* mat_out, uint32_t* ftag_out) {
     uint32_t type, mat;
     PtRay local;
@@ -614,7 +626,11 @@ PT_HD bool pt_hit_surface(const PtSceneView& sc, const PtRay& ray, const PtHit& 
                 Nw = pt_xform_dir(sc.g_nrm + 9 * (size_t)sc.chain[k], 3, Nw);
             }
         } else {
+            const uint32_t rec0 = rec[0];
             for (uint32_t k = len; k-- > 0u;) {
+                // A level whose matrices are the identity (pt_api.hip marks them in the record: a group without a transform, like every reference scene's
+                // root) changes no bit of a point or a direction whose components are finite and not -0: ((1 x + 0 y) + 0 z) + 0 is x. Skipped then (round 4).
+                if (SKIP_IDENT && ((rec0 >> (8u + k)) & 1u) && pt_identity_safe(P) && pt_identity_safe(Nw)) continue;
                 const uint32_t g = rec[1 + k];
                 P = pt_xform_point(sc.g_fwd + 12 * (size_t)g, P);
                 Nw = pt_xform_dir(sc.g_nrm + 9 * (size_t)g, 3, Nw);
@@ -825,9 +841,9 @@ PT_ADVANCE_ATTR void pt_lane_advance(const PtRenderArgs& a, PtLane& L, const PtH
             PtVec3 P, N;
             uint32_t mat, ftag;
 #ifdef PT_MAPS_BEFORE
-            pt_hit_surface<TEX, HIER, true>(sc, L.ray, hit, &P, &N, &mat, &ftag);
+            pt_hit_surface<TEX, HIER, true, true>(sc, L.ray, hit, &P, &N, &mat, &ftag);
 #else
-            pt_hit_surface<TEX, HIER>(sc, L.ray, hit, &P, &N, &mat, &ftag);
+            pt_hit_surface<TEX, HIER, false, true>(sc, L.ray, hit, &P, &N, &mat, &ftag);
 #endif
             fr.set_l3(PT_L_P, P);
             PT_FENCE;
