@@ -295,6 +295,27 @@ def test_mesh_free_scene_without_reflection_matches_oracle(oracle, host, H, seed
     assert_ulp(linear, ref.linear, 0)
 
 
+@pytest.mark.parametrize("seed", [2, 5])
+@pytest.mark.parametrize("stats", [True, False])
+def test_kd_kdmesh_interpreter_without_parked_frame(oracle, host, H, seed, stats, monkeypatch):
+    """PORTRAYER_PARK=0 (every recursion frame in HBM) in the k-d semantics of a scene with KDMesh trees: interpreter variant 0 of mode 2, whose COUNTING
+    instantiation - the most register-starved kernel of the library - was found rendering wrongly at the end of round 4 (two thirds of the hits lost; the plain
+    instantiation, -O1 builds and builds without the re-read of the kernel arguments were right): pt_render_kernel.h keeps the re-read out of it. This test is what
+    notices if that instantiation goes wrong again."""
+    monkeypatch.setenv("PORTRAYER_PARK", "0")
+    scene, cam = random_scene(seed)
+    r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_KD, kd_depth=6)
+    w, h = 112, 80
+    rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), samples=1, seed=seed, sample_mode=H.SAMPLE_CENTRE, stats=stats)
+    assert st["kernel_mode"] == 2 and st["kernel_variant"] & H.KERNEL_INTERPRETER and not st["kernel_variant"] & H.KERNEL_PARK
+    assert bool(st["kernel_variant"] & H.KERNEL_COUNTING) == stats
+    ref = oracle.render(oracle.pack(scene), cam, w, h, samples=1, seed=seed, jitter=oracle.JITTER_CENTRE, mode=oracle.MODE_KD, kd_depth=6)
+    if stats:
+        for k in ("primary", "shadow", "reflect", "refract", "hits"):
+            assert st[k] == ref.stats[k], k
+    assert not (rgb != ref.rgb).any()
+
+
 @pytest.mark.parametrize("seed", range(8))
 @pytest.mark.parametrize("mode", ["flat", "kd"])
 def test_random_scene_matches_oracle(oracle, host, H, seed, mode):
