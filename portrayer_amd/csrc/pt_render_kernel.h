@@ -156,7 +156,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
             // 93 spilled scalar registers): built that way it loses two thirds of its hits (c55 - c58, profiles/r04/notes.md section 11) while the same source at -O1, with
             // per-lane walks, or without this re-read renders correctly - a code generation problem of the most register-starved kernel in the library, not understood;
             // tests/test_gpu_render_parity.py::test_kd_kdmesh_interpreter_without_parked_frame guards the instantiation.
+#ifdef PT_ARGS_AGAIN_EVERYWHERE  // (reproduces the wrong render: profiles/r04/park0_probe3.py)
+            constexpr bool again = true;
+#else
             constexpr bool again = !(MODE == PT_MODE_KD && STATS && VAR == 0);
+#endif
             const PtRenderArgs& a = again ? pt_args_again(a0) : a0;
 #endif
             constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH || MODE == PT_MODE_HIER_MESH;
