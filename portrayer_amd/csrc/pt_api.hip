@@ -1158,11 +1158,12 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     if (const char* e = getenv("PORTRAYER_BATCH_MAX")) a.batch_max = (uint32_t)std::max(1, atoi(e));
     // The queues also win wherever a wavefront gets few items (a small frame, one GPU's share of a frame: big-scene's 1/8 share +8 %,
     // macho-cows +13 %) and on the mesh-heavy scenes (+3-7 %); very long launches (> 2048 items per resident wavefront: 3840x2160x256)
-    // and the k-d tree semantics are 1 % better off with batches.
+    // are 1 % better off with batches.
     const uint64_t resident_waves = (uint64_t)grid * (PT_BLOCK / 64);
     const bool long_launch = (uint64_t)a.n_items > 2048ull * std::max<uint64_t>(resident_waves, 1);
     const bool kd_mode = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH || a.scene.mode == PT_MODE_KD_MESH;
-    a.fine_queues = (c->spawns || (!long_launch && !kd_mode)) ? 16 : 0;  // 8 .. 32 queues measured alike, 64 and 4 about 1 % behind
+    // (round 3's per-lane k-d walk was 1 % better off with batches; the wave-uniform one is not: big-scene +1.1 %, macho-cows +3.2 % with the queues, round 4 c68)
+    a.fine_queues = (c->spawns || !long_launch) ? 16 : 0;  // 8 .. 32 queues measured alike, 64 and 4 about 1 % behind
     if (const char* e = getenv("PORTRAYER_FINE_QUEUES")) a.fine_queues = (uint32_t)std::max(0, std::min(PT_FINE_QUEUES, atoi(e)));
     a.item_stride = 1;
     if (const char* e = getenv("PORTRAYER_ITEM_STRIDE")) {  // experiment (batches only): position q -> item (q * stride) mod n; "golden" = 0.618 n
