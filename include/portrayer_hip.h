@@ -129,7 +129,10 @@ typedef struct {
 } pt_scene;
 
 /* The scene k-d tree the host built (KDTreeScene::from, src/kdtree/kdscene.rs:19-43), linearised;
- * node 0 is the root. Needed for PT_TRAVERSE_KD only. */
+ * node 0 is the root. Needed for PT_TRAVERSE_KD only.
+ * Limits (pt_scene_upload fails with PT_ERR_SCENE beyond them): at most 32 split levels on any path
+ * from the root (the reference's KD_DEPTH defaults to 10, kdscene.rs:36; a tree deeper than 32 has more
+ * than 2^32 leaves unless it is a degenerate chain), fewer than 2^26 nodes, fewer than 2^27 leaf items. */
 typedef struct {
     uint32_t n_nodes;
     const int32_t *axis;      /* 0,1,2: KDTreeNode::Split on that axis; -1: KDTreeNode::Leaf (node.rs:13-25) */

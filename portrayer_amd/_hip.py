@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libportrayer_hip.so")
 
 TRAVERSE_FLAT, TRAVERSE_KD, TRAVERSE_HIER = 1, 2, 3
 SAMPLE_CENTRE, SAMPLE_RNG = 0, 1
+# the header's error codes (include/portrayer_hip.h: every entry point returns 0 or one of these)
+OK, ERR_ARGUMENT, ERR_DEVICE, ERR_NO_SCENE, ERR_SLICE, ERR_SCENE, ERR_TRAVERSAL = 0, -1, -2, -3, -4, -5, -6
 # pt_stats.kernel_variant (ABI 6): low four bits = waves per SIMD
 KERNEL_WAVES_MASK, KERNEL_INTERPRETER, KERNEL_PARK, KERNEL_COUNTING, KERNEL_TEXTURED, KERNEL_FORK, KERNEL_CHAIN = 15, 16, 32, 64, 128, 256, 512
 

@@ -712,7 +712,10 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         }
     }
     if (kd_levels > PT_KD_WAVE_LEVELS)  // two bits of per-lane state per level in one 64-bit word (pt_trace_packet_kd); a tree that deep has > 2^32 leaves unless it is a degenerate chain
-        return pt_fail(c, PT_ERR_SCENE, "k-d tree deeper than 32 levels");
+        return pt_fail(c, PT_ERR_SCENE, "k-d tree deeper than 32 levels (the limit of the k-d walk: include/portrayer_hip.h, pt_kdtree)");
+    // what the walk's packed words can address: a stack entry is (node << 5) | level, a node is fetched at byte offset node << 6, a leaf reference at (first + i) << 5
+    if (kdn.size() >= ((size_t)1 << 26)) return pt_fail(c, PT_ERR_SCENE, "k-d tree of 2^26 nodes or more");
+    if (kd_ref32.size() / 8 >= ((size_t)1 << 27)) return pt_fail(c, PT_ERR_SCENE, "k-d tree with 2^27 leaf references or more");
     std::vector<float> kd_box32;
     if (traverse == PT_TRAVERSE_KD) {  // children follow their parents in the linearised tree (pre-order): one backward sweep
         kd_box32.assign(6 * kdn.size(), 0.0f);

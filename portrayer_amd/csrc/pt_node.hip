@@ -129,6 +129,7 @@ struct pt_node {
     size_t bg_ready_bytes = 0;  // size of the background pt_node_upload_background left on every rank
     uint64_t frame_begun = 0, frame_ended = 0;  // frames begun / closed (begun - ended <= PT_NODE_FRAMES)
     uint64_t frame_used[PT_NODE_FRAMES] = {0, 0};  // how often a buffer set has been used (its `gathered` events are valid from the first use on)
+    int fail_after_launch = -1;  // PORTRAYER_NODE_FAIL_AFTER_LAUNCH=<rank> (tests): see pt_node_frame_begin
     double host_ms[5] = {0, 0, 0, 0, 0};   // of the last frame: begin (launches + gather queued), wait (blocked until the image is complete), finish (flags, counters), per-rank launch (the slowest), the ranks' kernel times added up
 };
 
@@ -186,6 +187,7 @@ extern "C" int pt_node_create(int n_devices, const int* devices, pt_node** out) 
     }
     bool threads = ranks > 1;
     if (const char* e = getenv("PORTRAYER_NODE_THREADS")) threads = atoi(e) > 0;
+    if (const char* e = getenv("PORTRAYER_NODE_FAIL_AFTER_LAUNCH")) n->fail_after_launch = atoi(e);
     if (threads) {
         n->worker.assign(ranks, nullptr);
         for (size_t r = 0; r < ranks; r++) { n->worker[r] = new RankWorker(); n->worker[r]->start(); }
@@ -238,6 +240,8 @@ extern "C" pt_context* pt_node_context(pt_node* n, int rank) { return (n && rank
 
 extern "C" int pt_node_scene_upload(pt_node* n, const pt_scene* scene, int traverse, const pt_kdtree* kd) {
     if (!n || !scene) return PT_ERR_ARGUMENT;
+    // the scene buffers are read by the renders of open frames (non-blocking streams: the upload's synchronous copies are not ordered against them)
+    if (n->frame_begun != n->frame_ended) return node_fail(n, PT_ERR_ARGUMENT, "frames are in flight: pt_node_frame_end first");
     n->have_scene = false;
     for (size_t r = 0; r < n->ctx.size(); r++) NODE_CTX(n, r, pt_scene_upload(n->ctx[r], scene, traverse, kd));  // replicated: <= ~100 MB even for 1.25 M triangles
     n->have_scene = true;
@@ -260,9 +264,10 @@ extern "C" int pt_node_upload_background(pt_node* n, const double* background, c
     const uint32_t ranks = (uint32_t)n->ctx.size();
     const size_t px = (size_t)params->width * params->height;
     const size_t bg_bytes = (params->background_rows ? (size_t)params->height : px) * 3 * sizeof(double);
+    // before anything is reallocated: an open frame's untile targets d_full, its renders read d_bg
+    if (n->frame_begun != n->frame_ended) return node_fail(n, PT_ERR_ARGUMENT, "frames are in flight: pt_node_frame_end first");
     if ((rc = node_reserve(n, n->devices[0], &n->d_full, &n->full_bytes, px * 3))) return rc;
     NODE_HIP(n, hipSetDevice(n->devices[0]));
-    if (n->frame_begun != n->frame_ended) return node_fail(n, PT_ERR_ARGUMENT, "frames are in flight: pt_node_frame_end first");
     // pixels outside the slice keep the caller's bytes (render.rs:135-138); without a caller's image they are zero, not whatever the buffer held
     if (rgb) NODE_HIP(n, hipMemcpyAsync(n->d_full, rgb, px * 3, hipMemcpyHostToDevice, n->gstream[0]));
     else NODE_HIP(n, hipMemsetAsync(n->d_full, 0, px * 3, n->gstream[0]));
@@ -324,6 +329,7 @@ extern "C" int pt_node_frame_begin(pt_node* n, const pt_camera* camera, const pt
     const bool reuse = n->frame_used[f] > 0;
     // per rank: wait until the buffer set's previous frame has been sent, render, mark, and let the gather stream wait for the mark
     std::vector<double> launch_ms(ranks, 0.0);
+    std::vector<std::string> hip_after_launch(ranks);  // a HIP call behind a rank's launch failed: its text (the launch itself is open and must be closed)
     auto launch = [&, f, reuse](uint32_t r) {
         const auto l0 = std::chrono::steady_clock::now();
         int rr = PT_OK;
@@ -336,11 +342,14 @@ extern "C" int pt_node_frame_begin(pt_node* n, const pt_camera* camera, const pt
             if (rr == PT_OK) {
                 e = hipEventRecord(n->done[f][r], n->stream[r]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(n->gstream[r], n->done[f][r], 0);
-                if (e != hipSuccess) rr = PT_ERR_DEVICE + 1000;  // launched, then a HIP call failed: still to be closed
+                if (e != hipSuccess) { rr = PT_ERR_DEVICE; hip_after_launch[r] = std::string("a HIP call behind its launch failed: ") + hipGetErrorString(e); }  // launched: still to be closed
             }
         } else {
             rr = PT_ERR_DEVICE;
+            hip_after_launch[r] = std::string("before its launch: ") + hipGetErrorString(e);
         }
+        // fault injection (tests of this error path; read once in pt_node_create): the rank reports a failed HIP call behind a launch that did go out
+        if (n->fail_after_launch == (int)r && rr == PT_OK) { rr = PT_ERR_DEVICE; hip_after_launch[r] = "a HIP call behind its launch failed: injected (PORTRAYER_NODE_FAIL_AFTER_LAUNCH)"; }
         n->rank_rc[r] = rr;
         launch_ms[r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - l0).count();
     };
@@ -354,8 +363,8 @@ extern "C" int pt_node_frame_begin(pt_node* n, const pt_camera* camera, const pt
     n->frame_used[f]++;
     for (uint32_t r = 0; r < ranks; r++)
         if (n->rank_rc[r] != PT_OK) {
-            std::string why = n->rank_rc[r] >= 1000 ? "a HIP call behind its launch failed" : pt_last_error(n->ctx[r]);
-            const int code = n->rank_rc[r] >= 1000 ? PT_ERR_DEVICE : n->rank_rc[r];
+            const std::string why = !hip_after_launch[r].empty() ? hip_after_launch[r] : std::string(pt_last_error(n->ctx[r]));  // (read before node_drain touches the context)
+            const int code = n->rank_rc[r];  // always one of the header's negative codes
             node_drain(n);
             return node_fail(n, code, "rank " + std::to_string(r) + ": " + why);
         }

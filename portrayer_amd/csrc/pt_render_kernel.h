@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "pt_shade.h"
 
@@ -313,24 +314,29 @@ static hipError_t pt_launch_kernel(size_t lds, const PtRenderArgs& a, int n_cu, 
     constexpr auto kernel = KERNEL;
     struct PerDevice { size_t lds_allowed = 64 * 1024; size_t occ_lds = ~(size_t)0; int per_cu = 0; };
     static PerDevice state[PT_MAX_DEVICES];  // one per kernel instantiation and device
+    static std::mutex state_lock;            // pt_node launches every rank from its own host thread, and ranks may share a device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     PerDevice local;
     PerDevice& st = (dev >= 0 && dev < PT_MAX_DEVICES) ? state[dev] : local;
+    int per_cu = 0;
+    {
+    std::lock_guard<std::mutex> hold(state_lock);  // (held over the two runtime calls as well: they happen once per (kernel, device, LDS size))
     if (lds > st.lds_allowed) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per block must be asked for
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         st.lds_allowed = lds;
     }
     if (st.occ_lds != lds) {
-        int per_cu = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PT_BLOCK, lds);
+        int occ = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, PT_BLOCK, lds);
         if (e != hipSuccess) return e;
-        st.per_cu = per_cu < 1 ? 1 : per_cu;
+        st.per_cu = occ < 1 ? 1 : occ;
         st.occ_lds = lds;
     }
-    int per_cu = st.per_cu;
+    per_cu = st.per_cu;
+    }
     uint32_t want = (a.n_items + (PT_BLOCK / 64) - 1) / (PT_BLOCK / 64);
     if (const char* env = getenv("PORTRAYER_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(env)));  // experiment: fewer resident lanes
     uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));

@@ -1801,7 +1801,8 @@ PT_HD double pt_kd_sav_load(const PtKdSav& s, int level) {
 #ifndef PT_KD_WALK_STEPS_MAX
 #define PT_KD_WALK_STEPS_MAX (1u << 26)  // more nodes than a k-d tree of 2^26 nodes (the limit of the 32-bit byte offsets) has
 #endif
-#define PT_KD_WAVE_LEVELS 32  // two bits per level in a 64-bit word per lane; deeper trees keep the per-lane walk (PtKdWalker)
+#define PT_KD_WAVE_LEVELS 32  // two bits per level in a 64-bit word per lane. pt_scene_upload REFUSES deeper trees (PT_ERR_SCENE; include/portrayer_hip.h says so):
+                              // the render kernels have no other k-d walk (the per-lane PtKdWalker serves pt_test_cast_rays and -DPT_NO_PACKET builds only)
 
 // Mesh::ray_hit below a k-d leaf (mesh.rs:146-167) for the lanes in `part`: the instance's triangle tree walked once per wavefront
 // like pt_trace_packet_mesh does, every triangle tested over [start, end of the lane's leaf fold) - nearest triangle, lowest index on

@@ -58,7 +58,12 @@ def test_roofline_block_shape(bench):
     r = bench.roofline_block("no-such-workload/flat/gpus1", True, st, 1.0e9, 0.01, 6000.0, counts, counts, 300, 3, "flat", 5.0e8)
     f64, f32, flops = bench.algorithmic_ops(counts, 3, "flat")
     assert r["bound"] == "valu" and r["peak"] == 39.3 and r["traffic"] is None
-    assert r["achieved"] == pytest.approx((f64 + 0.5 * f32) / 0.01 / 1e12) and r["frac"] == pytest.approx(r["achieved"] / 39.3)
+    # the top-level figure counts the 17 instructions the shipped mesh-free step issues per node visit, one slot each; the textbook one stays in tree_step
+    assert r["achieved"] == pytest.approx((f64 + 17 * counts["n_inner"]) / 0.01 / 1e12) and r["frac"] == pytest.approx(r["achieved"] / 39.3)
+    assert r["frac"] == pytest.approx(r["valu"]["tree_step"]["frac_with_the_shipped_step"])
+    assert r["f64_frac"] == pytest.approx(f64 / 0.01 / 1e12 / 39.3) and r["f64_frac"] < r["frac"] and r["issue_frac"] is None  # (no committed profile of this made-up workload)
+    kd = bench.roofline_block("no-such-workload/kd/gpus1", True, dict(st, kernel_mode=7), 1.0e9, 0.01, 6000.0, counts, counts, 300, 3, "kd", 5.0e8)
+    assert kd["frac"] == pytest.approx(kd["f64_frac"])  # the k-d semantics have no box step of the builder's in the formula: f64 work only
     assert r["hbm"]["needed_bytes"] == 5.0e8 and r["hbm"]["measured_bytes"] is None and r["hbm"]["waste_ratio"] is None and "no PMC profile" in r["hbm"]["profile"]
     assert r["algorithmic"]["GBps"] == pytest.approx(100.0) and r["kernel"].startswith("void pt_render_simple_kernel<3, false, false, 4, false>")
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))

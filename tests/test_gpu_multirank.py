@@ -245,6 +245,56 @@ def test_node_frames_in_a_pipeline(H, monkeypatch, ranks, threads):
     lib.pt_node_destroy(node)
 
 
+def test_node_failure_behind_a_launch_and_uploads_under_open_frames(H, monkeypatch):
+    """(1) a HIP call that fails BEHIND a rank's launch must come back as one of the header's negative codes with its own
+    text (the old sentinel PT_ERR_DEVICE + 1000 = 998 was positive and never recognised), the launches that did go out closed, and the
+    node usable afterwards; (2) pt_node_upload_background / pt_node_scene_upload are refused while frames are open BEFORE they touch a
+    buffer - the open frame still delivers its image."""
+    import device_glue
+    from example_scenes import EXAMPLES
+    scene, cam, _ = EXAMPLES["macho-cows"]()
+    ds = device_glue.DeviceScene(scene, H.TRAVERSE_FLAT)
+    lib = H.lib()
+    w, h = 96, 64
+    bg = default_background(w, h)
+    ctx = H.Context()
+    ds.upload(ctx)
+    one, _, _ = device_glue.render(ctx, cam, w, h, samples=2, seed=4, sample_mode=H.SAMPLE_RNG)
+    ctx.close()
+    p = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), 2, 4, H.SAMPLE_RNG, 1, 0, 1, 1)
+    big = H.PtRenderParams(2 * w, 2 * h, H.PtRect(0, 0, 2 * w - 1, 2 * h - 1), 2, 4, H.SAMPLE_RNG, 1, 0, 1, 1)
+    bg_big = default_background(2 * w, 2 * h)
+    camera = device_glue.camera_struct(cam, w, h)
+    devs = (C.c_int32 * 3)(0, 0, 0)
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    # (1) the injected failure
+    monkeypatch.setenv("PORTRAYER_NODE_FAIL_AFTER_LAUNCH", "1")
+    node = C.c_void_p()
+    assert lib.pt_node_create(3, devs, C.byref(node)) == 0
+    assert lib.pt_node_scene_upload(node, C.byref(ds.struct), H.TRAVERSE_FLAT, None) == 0
+    assert lib.pt_node_upload_background(node, bg.ctypes.data_as(H._dp), C.byref(p), None) == 0
+    rc = lib.pt_node_frame_begin(node, C.byref(camera), C.byref(p))
+    assert rc == H.ERR_DEVICE and rc < 0, rc
+    msg = lib.pt_node_last_error(node).decode()
+    assert "rank 1" in msg and "behind its launch" in msg, msg
+    assert lib.pt_node_frames_in_flight(node) == 0  # drained and closed
+    lib.pt_node_destroy(node)
+    monkeypatch.delenv("PORTRAYER_NODE_FAIL_AFTER_LAUNCH")
+    # (2) uploads under an open frame
+    node = C.c_void_p()
+    assert lib.pt_node_create(3, devs, C.byref(node)) == 0
+    assert lib.pt_node_scene_upload(node, C.byref(ds.struct), H.TRAVERSE_FLAT, None) == 0
+    assert lib.pt_node_upload_background(node, bg.ctypes.data_as(H._dp), C.byref(p), None) == 0
+    assert lib.pt_node_frame_begin(node, C.byref(camera), C.byref(p)) == 0, lib.pt_node_last_error(node)
+    assert lib.pt_node_upload_background(node, bg_big.ctypes.data_as(H._dp), C.byref(big), None) == H.ERR_ARGUMENT  # a LARGER image: would have reallocated the open frame's target
+    assert lib.pt_node_scene_upload(node, C.byref(ds.struct), H.TRAVERSE_FLAT, None) == H.ERR_ARGUMENT
+    assert b"in flight" in lib.pt_node_last_error(node)
+    assert lib.pt_node_frame_end(node, None) == 0, lib.pt_node_last_error(node)
+    assert lib.pt_node_download_image(node, C.byref(p), img.ctypes.data_as(H._u8p)) == 0
+    assert np.array_equal(img, one)
+    lib.pt_node_destroy(node)
+
+
 def test_node_rccl_leg_inside_a_process_that_carries_torch(H):
     """bench.py drives pt_node from a process that has imported torch - which brings its own bundled RCCL - while pt_node dlopens the
     system's librccl: the combination the driver's multi-GPU run uses and no test had executed. A subprocess (so that this

@@ -82,6 +82,8 @@ def test_example_matches_oracle(oracle, host, H, name, size, mode):
     r = host.Renderer(sc, H.TRAVERSE_KD if mode == "kd" else H.TRAVERSE_FLAT)
     bg = default_background(w, h)
     rgb, linear, st = r.render(sc.camera, w, h, bg, stats=True)
+    # ... and the PLAIN instantiation, the one a user's render runs (render.rs:127-150): same image, same f64 means
+    plain, plain_linear, st0 = r.render(sc.camera, w, h, bg)
     cam = EXAMPLES[name]()[1]
     ref = oracle.render(oracle_from(oracle, sc), cam, w, h, mode=oracle.MODE_KD if mode == "kd" else oracle.MODE_FLAT)
     assert np.array_equal(rgb, ref.rgb)
@@ -89,6 +91,10 @@ def test_example_matches_oracle(oracle, host, H, name, size, mode):
     for k in ("primary", "shadow", "reflect", "refract", "hits"):
         assert st[k] == ref.stats[k], k
     assert st["stack_overflow"] == 0 and st["kd_plane_miss"] == 0
+    assert st["kernel_variant"] & H.KERNEL_COUNTING and not (st0["kernel_variant"] & H.KERNEL_COUNTING)
+    assert st0["kernel_mode"] == st["kernel_mode"] and (st0["kernel_variant"] | H.KERNEL_COUNTING) == st["kernel_variant"]
+    assert np.array_equal(plain, ref.rgb)
+    assert_ulp(plain_linear, ref.linear, 0)
     r.close()
 
 
