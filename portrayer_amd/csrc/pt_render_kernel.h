@@ -153,16 +153,11 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_VAR_WAVES(VAR)) pt_render_kernel(
 #endif
 #ifndef PT_NO_ARGS_AGAIN
             // what the interpreter and this pass's walk need of the arguments is fetched now, not kept from the top of the kernel on (pt_render_simple.h).
-            // NOT in the counting instantiation of the k-d semantics with KDMesh trees without a parked frame in LDS (<PT_MODE_KD, true, *, 0>: 180 spilled vector and
-            // 93 spilled scalar registers): built that way it loses two thirds of its hits (c55 - c58, profiles/r04/notes.md section 11) while the same source at -O1, with
-            // per-lane walks, or without this re-read renders correctly - a code generation problem of the most register-starved kernel in the library, not understood;
-            // tests/test_gpu_render_parity.py::test_kd_kdmesh_interpreter_without_parked_frame guards the instantiation.
-#ifdef PT_ARGS_AGAIN_EVERYWHERE  // (reproduces the wrong render: profiles/r04/park0_probe3.py)
-            constexpr bool again = true;
-#else
-            constexpr bool again = !(MODE == PT_MODE_KD && STATS && VAR == 0);
-#endif
-            const PtRenderArgs& a = again ? pt_args_again(a0) : a0;
+            // (Round 4 kept this out of <PT_MODE_KD, true, *, 0>, which rendered wrongly with it. Round 5 found why - the compiler's vector register
+            // allocator had put a spill store of `best.t` in front of the s_or_b64 exec that re-converges the block, so the lanes that sat out a leaf lost
+            // their nearest hit: profiles/r05/notes.md section 1 - and the build now checks and repairs every kernel's assembly for it
+            // (tools/check_exec_prologue.py), so no instantiation is special any more.)
+            const PtRenderArgs& a = pt_args_again(a0);
 #endif
             constexpr bool HIER = MODE == PT_MODE_HIER || MODE == PT_MODE_HIER_NOMESH || MODE == PT_MODE_HIER_MESH;
             uint32_t pre = 0;

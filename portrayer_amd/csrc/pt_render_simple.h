@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
     const PtRenderArgs& a = a0;
     const uint32_t lane_global = blockIdx.x * PT_BLOCK + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
-    const PtSceneView& sc = a.scene;
+    [[maybe_unused]] const PtSceneView& sc = a.scene;  // (shadowed per item by the re-read arguments' view unless -DPT_NO_ARGS_AGAIN)
     PtStackSpill stk;
     stk.base = pt_lds + threadIdx.x;
     stk.cap = a.stack_lds_cap;

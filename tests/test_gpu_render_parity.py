@@ -305,9 +305,11 @@ def test_mesh_free_scene_without_reflection_matches_oracle(oracle, host, H, seed
 @pytest.mark.parametrize("stats", [True, False])
 def test_kd_kdmesh_interpreter_without_parked_frame(oracle, host, H, seed, stats, monkeypatch):
     """PORTRAYER_PARK=0 (every recursion frame in HBM) in the k-d semantics of a scene with KDMesh trees: interpreter variant 0 of mode 2, whose COUNTING
-    instantiation - the most register-starved kernel of the library - was found rendering wrongly at the end of round 4 (two thirds of the hits lost; the plain
-    instantiation, -O1 builds and builds without the re-read of the kernel arguments were right): pt_render_kernel.h keeps the re-read out of it. This test is what
-    notices if that instantiation goes wrong again."""
+    instantiation - the most register-starved kernel of the library - was found rendering wrongly at the end of round 4 (two thirds of the hits lost).
+    Round 5 root-caused it (profiles/r05/notes.md section 1): hipcc's vector register allocator had put the spill store of the walk's `best.t` in FRONT of the
+    s_or_b64 exec that re-converges a block, so the lanes that sat out a k-d leaf lost their nearest hit. The build now runs every kernel's assembly through
+    tools/check_exec_prologue.py, which repairs exactly this block of exactly this instantiation; the instantiation is built like all the others again.
+    This test is the render that was wrong."""
     monkeypatch.setenv("PORTRAYER_PARK", "0")
     scene, cam = random_scene(seed)
     r = host.Renderer(host_glue.host_scene(scene), H.TRAVERSE_KD, kd_depth=6)
@@ -470,6 +472,8 @@ def test_chain_kernel_matches_interpreter_and_oracle(oracle, host, H, monkeypatc
     kernel with a loop over the depth (pt_render_simple.h, CHAIN) instead of the interpreter; PORTRAYER_CHAIN=0 keeps the
     interpreter. Same image, same f64 means, same ray counts - and the oracle's: perfect mirrors facing each other (chains the
     depth limit ends, material.rs:102-104), glossy draws after area-light draws, meshes, instancing."""
+    for k in ("PORTRAYER_PARK", "PORTRAYER_CHAIN", "PORTRAYER_CHAIN_WAVES"):  # this test picks the kernels itself (the suite may be running under a switch: tests/test_gpu_switch_matrix.py)
+        monkeypatch.delenv(k, raising=False)
     scene, cam = random_scene(100 + seed, dielectric=False)
     tr, om = {"flat": (H.TRAVERSE_FLAT, oracle.MODE_FLAT), "kd": (H.TRAVERSE_KD, oracle.MODE_KD), "hier": (H.TRAVERSE_HIER, oracle.MODE_HIER)}[mode]
     w, h, samples = 128, 96, 3

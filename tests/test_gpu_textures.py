@@ -237,6 +237,8 @@ def test_fork_join_of_refracted_subtrees_matches_oracle(oracle, host, H, monkeyp
     and == the render without forking. 64 samples per pixel: a wavefront is one pixel, offers and idle lanes meet inside it."""
     from example_scenes import TEXTURED_EXAMPLES
     from scene_dsl import default_background
+    for k in ("PORTRAYER_FORK", "PORTRAYER_PARK"):  # this test picks the kernels itself
+        monkeypatch.delenv(k, raising=False)
     scene, cam = TEXTURED_EXAMPLES[scene_name]()[:2]
     tr, om = {"flat": (H.TRAVERSE_FLAT, oracle.MODE_FLAT), "kd": (H.TRAVERSE_KD, oracle.MODE_KD), "hier": (H.TRAVERSE_HIER, oracle.MODE_HIER)}[mode]
     w, h, samples = 96, 54, 64
