@@ -17,8 +17,8 @@ kernel, round 4's wrong counting render of pt_render_kernel<2, true, *, 0>; root
     the lanes that sat out the divergent region never store their value; the reload (full exec) hands them whatever the slot held.
 
 This script reads device assembly (hipcc --offload-device-only -S) and reports the vector code only a register allocator inserts - spill stores and
-reloads ("Folded Spill" / "Folded Reload"), register-to-register moves - that stands between the start of a LABELLED basic block (a branch target: the join
-of a divergent region) and the exec-widening instruction that opens it, with nothing but scalar instructions around it.
+reloads ("Folded Spill" / "Folded Reload"), register-to-register moves - that stands between the label an `s_cbranch_execz` skips a divergent region to (the JOIN) and the `s_or_b64 exec, exec, sX` with that branch's saved exec
+mask, with nothing but scalar instructions around it.
 usage: check_exec_prologue.py file.s [file.s ...]              exit code 1 if any spill is found in front of an exec restore
        check_exec_prologue.py --fix in.s -o out.s             writes the assembly with every such block REPAIRED - the exec-widening instruction
                                                               moved in front of the spill code, which is where the allocator meant it to be: the
@@ -42,6 +42,37 @@ SPILL = ("Folded Spill", "Folded Reload")
 COPY = re.compile(r"^\s*(v_mov_b32_e32\s+v\d+,\s*v\d+\s*(;.*)?$|v_mov_b64_e32\s+v\[\d+:\d+\],\s*v\[\d+:\d+\]\s*(;.*)?$|v_accvgpr_(read|write)_b32\s)")
 
 
+SAVE = re.compile(r"^\s*(s_and_saveexec_b64|s_or_saveexec_b64|s_andn2_saveexec_b64|s_xor_saveexec_b64)\s+(s\[\d+:\d+\]|vcc),|^\s*s_xor_b64\s+(s\[\d+:\d+\]|vcc),\s*exec,")
+SKIP = re.compile(r"^\s*s_cbranch_execz\s+(\.LBB\d+_\d+)")
+
+
+def joins(lines):
+    """label -> the saved-exec registers of the `s_cbranch_execz label` branches that skip a divergent region to it (the register written by the
+    s_and_saveexec_b64 / s_xor_b64 .., exec, .. in front of the branch). Only such a label is a JOIN: lanes that sat the region out arrive there with
+    their exec bits cleared, and the block's `s_or_b64 exec, exec, <that register>` brings them back. (A label entered with s_cbranch_execnz is the region's
+    own body - possibly with the join's code duplicated behind it -, and vector code in front of an exec restore there is the program's.)"""
+    out = {}
+    saved = None
+    for raw in lines:
+        line = raw.rstrip("\n")
+        if BLOCK.match(line):
+            saved = None
+            continue
+        m = SAVE.match(line)
+        if m:
+            saved = m.group(2) or m.group(3)
+            continue
+        m = SKIP.match(line)
+        if m and saved:
+            out.setdefault(m.group(1), set()).add(saved)
+    return out
+
+
+def restores(line, regs):
+    m = re.match(r"^\s*s_or_b64\s+exec,\s*exec,\s*(s\[\d+:\d+\]|vcc)", line)
+    return bool(m) and m.group(1) in regs
+
+
 def allocator_code(line):
     """vector instructions only the register allocator puts at the start of a block: spill stores / reloads and live-range-split copies"""
     return any(t in line for t in SPILL) or COPY.match(line) is not None
@@ -55,17 +86,22 @@ def scan(path):
     defects = []
     func = "?"
     label = "?"
-    zone = True      # still inside the prologue zone of the current block
-    pending = []     # spill code seen in the zone so far
+    zone = False     # inside the prologue zone of a join block
+    pending = []     # allocator code seen in the zone so far
+    regs = set()     # the saved-exec registers the join's restore may use
     with open(path, errors="replace") as fh:
-        for ln, raw in enumerate(fh, 1):
+        lines = fh.readlines()
+    join = joins(lines)
+    if True:
+        for ln, raw in enumerate(lines, 1):
             line = raw.rstrip("\n")
             m = FUNC.match(line)
             if m and not line.startswith(".L"):
                 func = m.group(1)
             if BLOCK.match(line):
-                pending, zone = [], not line.startswith(";")   # (a fall-through block "; %bb.N:" is no join: its leading code belongs to the region it continues)
                 label = line.split(":")[0].strip()
+                regs = join.get(label, set())
+                pending, zone = [], bool(regs)   # (only a JOIN opens a zone: see joins())
                 continue
             s = line.strip()
             if not s or s.startswith((";", ".", "//")):
@@ -73,8 +109,9 @@ def scan(path):
             if not zone:
                 continue
             if WIDEN.match(line):
-                for (pl, pt) in pending:
-                    defects.append((path, func, label, pl, pt.strip(), s))
+                if restores(line, regs):
+                    for (pl, pt) in pending:
+                        defects.append((path, func, label, pl, pt.strip(), s))
                 pending, zone = [], False
             elif VECTOR.match(line) and not EXEC_FREE.match(line):
                 if allocator_code(line):
@@ -92,17 +129,20 @@ def repair(lines):
     of the first such spill instruction. Returns (new lines, [(function, block, moved instruction, spill instructions)])."""
     out, log = [], []
     func, label = "?", "?"
-    zone = True
-    first_spill = None   # index in `out` of the first spill instruction of the current block's zone
+    zone = False
+    first_spill = None   # index in `out` of the first allocator instruction of the current join block's zone
     spills = []
+    join = joins(lines)
+    regs = set()
     for raw in lines:
         line = raw.rstrip("\n")
         m = FUNC.match(line)
         if m and not line.startswith(".L"):
             func = m.group(1)
         if BLOCK.match(line):
-            zone, first_spill, spills = not line.startswith(";"), None, []
             label = line.split(":")[0].strip()
+            regs = join.get(label, set())
+            zone, first_spill, spills = bool(regs), None, []
             out.append(raw)
             continue
         s = line.strip()
@@ -111,7 +151,7 @@ def repair(lines):
             continue
         if WIDEN.match(line):
             # (SI_ELSE is two instructions, s_or_saveexec_b64 + s_xor_b64 exec: not moved - such a block stays a reported defect and fails the build)
-            if first_spill is not None and re.match(r"^\s*s_or_b64\s+exec,\s*exec,", line):
+            if first_spill is not None and restores(line, regs):
                 out.insert(first_spill, raw)
                 log.append((func, label, s, [t.strip() for t in spills]))
             else:
