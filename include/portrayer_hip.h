@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 7
+#define PT_ABI_VERSION 8
 
 /* enum Primitive, src/primitive.rs:67-81 */
 enum { PT_PRIM_SPHERE = 0, PT_PRIM_TRIANGLE = 1, PT_PRIM_MESH = 2, PT_PRIM_KDMESH = 3, PT_PRIM_PLANE = 4, PT_PRIM_CUBE = 5, PT_PRIM_CYLINDER = 6, PT_PRIM_CONE = 7 };
@@ -224,6 +224,15 @@ int pt_render(pt_context *ctx, const pt_camera *camera, const double *background
 int pt_render_device(pt_context *ctx, const pt_camera *camera, const double *d_background, const pt_render_params *params,
                      int compact, void *d_rgb, void *hip_stream);
 int pt_render_finish(pt_context *ctx, pt_stats *stats);
+/* (ABI 8) Two renders of a context may be in flight at once - pt_render_device, pt_render_device, pt_render_finish (the OLDER one), ... - and since
+ * ABI 8 each of the two owns its work buffers, so that they may also run on two streams: pt_context_stream(ctx, k) is the context's own
+ * non-blocking stream (a hipStream_t) for the render that takes slot k & 1; pt_context_next_slot() says which slot the next pt_render_device
+ * takes (they are taken in turn). The render kernels are persistent: a frame's wavefronts retire one by one over the duration of its longest work
+ * items, and a next frame queued on the OTHER stream starts in the places they free instead of waiting for the last of them (the reference
+ * renders one image per call, src/render.rs:93-151; consecutive calls are independent, which is what lets two be in flight). For scenes whose
+ * kernels park recursion frames in HBM both slots get the SAME stream (two launches at once cost such scenes more than the tail is worth). */
+void *pt_context_stream(pt_context *ctx, int slot);
+int pt_context_next_slot(const pt_context *ctx);
 
 /* Bytes of one rank's compact tile buffer for a slice split over tile_ranks ranks (equal for all ranks). */
 uint64_t pt_compact_bytes(const pt_render_params *params);
@@ -276,6 +285,8 @@ int pt_node_frame_begin(pt_node *node, const pt_camera *camera, const pt_render_
 int pt_node_frame_end(pt_node *node, pt_stats *stats);
 int pt_node_frames_in_flight(const pt_node *node);
 int pt_node_last_frame_host_ms(const pt_node *node, double out[5]);
+/* (ABI 8) every rank's kernel time of the last frame closed, milliseconds (HIP events around the rank's launches); n_out = pt_node_ranks() */
+int pt_node_last_frame_rank_kernel_ms(const pt_node *node, double *out, int n_out);
 
 /* Device-side helpers used by the measurement harness. */
 int pt_device_alloc(pt_context *ctx, uint64_t bytes, void **out);

@@ -90,11 +90,11 @@ class PtStats(C.Structure):
 _lib: Optional[C.CDLL] = None
 
 EXPORTS = ["pt_abi_version", "pt_device_count", "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_scene_upload",
-           "pt_render", "pt_render_device", "pt_render_finish", "pt_compact_bytes", "pt_untile_device", "pt_tile_slot_pixel", "pt_untile_host", "pt_device_alloc",
+           "pt_render", "pt_render_device", "pt_render_finish", "pt_context_stream", "pt_context_next_slot", "pt_compact_bytes", "pt_untile_device", "pt_tile_slot_pixel", "pt_untile_host", "pt_device_alloc",
            "pt_device_free", "pt_copy_to_device", "pt_copy_from_device", "pt_synchronize", "pt_measure_copy_bandwidth", "pt_test_cast_rays",
            "pt_test_math", "pt_test_work_items", "pt_node_create", "pt_node_destroy", "pt_node_last_error", "pt_node_ranks", "pt_node_uses_rccl", "pt_node_context",
            "pt_node_scene_upload", "pt_node_render", "pt_node_upload_background", "pt_node_render_resident", "pt_node_download_image",
-           "pt_node_device", "pt_node_frame_begin", "pt_node_frame_end", "pt_node_frames_in_flight", "pt_node_last_frame_host_ms", "pt_test_pow_host", "pt_test_libm_host"]
+           "pt_node_device", "pt_node_frame_begin", "pt_node_frame_end", "pt_node_frames_in_flight", "pt_node_last_frame_host_ms", "pt_node_last_frame_rank_kernel_ms", "pt_test_pow_host", "pt_test_libm_host"]
 
 
 def header_functions():
@@ -133,6 +133,10 @@ def lib() -> C.CDLL:
         l.pt_render_device.argtypes = [C.c_void_p, C.POINTER(PtCamera), C.c_void_p, C.POINTER(PtRenderParams), C.c_int, C.c_void_p, C.c_void_p]
         l.pt_render_finish.restype = C.c_int
         l.pt_render_finish.argtypes = [C.c_void_p, C.POINTER(PtStats)]
+        l.pt_context_stream.restype = C.c_void_p
+        l.pt_context_stream.argtypes = [C.c_void_p, C.c_int]
+        l.pt_context_next_slot.restype = C.c_int
+        l.pt_context_next_slot.argtypes = [C.c_void_p]
         l.pt_compact_bytes.restype = C.c_uint64
         l.pt_compact_bytes.argtypes = [C.POINTER(PtRenderParams)]
         l.pt_untile_device.restype = C.c_int
@@ -191,6 +195,8 @@ def lib() -> C.CDLL:
         l.pt_node_frames_in_flight.argtypes = [C.c_void_p]
         l.pt_node_last_frame_host_ms.restype = C.c_int
         l.pt_node_last_frame_host_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double * 5)]
+        l.pt_node_last_frame_rank_kernel_ms.restype = C.c_int
+        l.pt_node_last_frame_rank_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         l.pt_test_pow_host.restype = C.c_int
         l.pt_test_pow_host.argtypes = [C.c_uint64, _dp, _dp, _dp, _dp]
         l.pt_test_libm_host.restype = C.c_int

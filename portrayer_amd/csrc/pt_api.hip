@@ -227,7 +227,7 @@ struct pt_context {
     PtBuf mat_maps, uv_trans, tex, tex_rgb, srgb_lut, tri_uv, texview, mkd, mkd_items;
     PtBuf node_box, kd_box, mkd_box, mkd_item_box, kd_ref;
     PtBuf g_inv, g_fwd, g_nrm, chain_off, chain, dfs_rank, hier_rec, own_inv;  // PT_TRAVERSE_HIER: the scene graph
-    PtBuf spill, stack_spill, accum, bg, rgb, linear, misc;  // misc: work counter + overflow flag (8 B), PtCounters at +256
+    PtBuf bg, rgb, linear, misc;  // (pt_render's host-buffer path; misc: pt_test_cast_rays' overflow flag)
     bool needs_spill = false;  // some material is reflective (recursion frames) or the scene has more than 32 lights
     bool spawns = false;       // some material is reflective: hits spawn rays, so the cost of a pixel varies by orders of magnitude
     bool one_ray = false;      // ... and every reflective material is opaque (no index of refraction): a hit spawns at most one ray, the recursion is a chain
@@ -243,8 +243,14 @@ struct pt_context {
     // Up to PT_SLOTS renders of one context may be in flight on a stream (pt_render_device ... pt_render_finish, oldest first): a frame's
     // events and the page of pinned host memory its overflow flag and counters are copied to - asynchronously, right behind its kernels -
     // belong to its slot, so closing a frame is an event wait and a read of host memory: no blocking copy, and the next frame may already
-    // be queued behind it (pt_node: frame k + 1 renders while frame k is gathered). The device-side buffers are shared: the stream orders them.
+    // be queued behind it (pt_node: frame k + 1 renders while frame k is gathered).
+    // Round 5: a slot also owns the launch's WORK buffers (chunk sums, recursion frames, stack overflow columns, work counters / queues / statistics) and a
+    // stream of its own (pt_context_stream), so that two frames may be in flight on two queues at once: the render kernels are persistent - a launch's
+    // wavefronts retire one by one over the duration of its longest work items (the TAIL: 0.13 ms of a 1.3 ms share of the headline frame, 11 %;
+    // profiles/r05/notes.md section 2) - and the next frame's wavefronts take the places they free instead of waiting for the last one.
     struct Slot {
+        PtBuf spill, stack_spill, accum, misc;     // misc: work counter + overflow flag (8 B), PtCounters at +256, the work queues behind them
+        hipStream_t stream = nullptr;              // pt_context_stream(ctx, slot): non-blocking, created with the context
         hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the kernels (pt_stats.kernel_ms)
         hipEvent_t copy_done = nullptr;            // behind the copy into `host`
         unsigned char* host = nullptr;   // pinned: [0, 8) work counter + overflow flag, [256, 256 + sizeof(PtCounters)) the counters
@@ -307,6 +313,7 @@ extern "C" int pt_context_create(int device, pt_context** out) {
     c->n_cu = prop.multiProcessorCount;
     for (auto& sl : c->slot)
         if (hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess || hipEventCreateWithFlags(&sl.copy_done, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
             hipHostMalloc((void**)&sl.host, PT_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) {
             pt_context_destroy(c);
             return PT_ERR_DEVICE;
@@ -320,9 +327,11 @@ extern "C" void pt_context_destroy(pt_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     PtBuf* bufs[] = {&c->inv, &c->fwd, &c->nrm, &c->info, &c->tri_v, &c->tri_e, &c->tri_leaf, &c->tri_n, &c->meshes, &c->materials, &c->lights,
-                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->spill, &c->stack_spill, &c->accum, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->kd_ref, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank, &c->hier_rec, &c->own_inv};
+                     &c->bvh, &c->bvh4, &c->bvh_items, &c->kd, &c->kd_items, &c->mat_maps, &c->uv_trans, &c->tex, &c->tex_rgb, &c->srgb_lut, &c->tri_uv, &c->texview, &c->mkd, &c->mkd_items, &c->slot[0].spill, &c->slot[0].stack_spill, &c->slot[0].accum, &c->slot[0].misc, &c->slot[1].spill, &c->slot[1].stack_spill, &c->slot[1].accum, &c->slot[1].misc, &c->bg, &c->rgb, &c->linear, &c->misc, &c->node_box, &c->kd_box, &c->mkd_box, &c->mkd_item_box, &c->kd_ref, &c->g_inv, &c->g_fwd, &c->g_nrm, &c->chain_off, &c->chain, &c->dfs_rank, &c->hier_rec, &c->own_inv};
     for (PtBuf* b : bufs) if (b->p) hipFree(b->p);
+    static_assert(pt_context::PT_SLOTS == 2, "the buffer list above names both slots");
     for (auto& sl : c->slot) {
+        if (sl.stream) { hipStreamSynchronize(sl.stream); hipStreamDestroy(sl.stream); }
         if (sl.ev0) hipEventDestroy(sl.ev0);
         if (sl.ev1) hipEventDestroy(sl.ev1);
         if (sl.copy_done) hipEventDestroy(sl.copy_done);
@@ -332,6 +341,20 @@ extern "C" void pt_context_destroy(pt_context* c) {
 }
 
 extern "C" const char* pt_last_error(const pt_context* c) { return c ? c->err.c_str() : "no context"; }
+
+// The context's own stream for the render that takes slot `slot & 1` (the slots are taken in turn: 0, 1, 0, ..): a caller that hands consecutive frames to
+// pt_render_device on pt_context_stream(ctx, k & 1) lets frame k + 1 start on the wavefront slots frame k's tail frees (see pt_context::Slot).
+// Scenes that park recursion frames in HBM (reflective materials: the chain and interpreter kernels) get ONE stream for both slots: two of their launches at
+// once double the frames' working set (277 MB per launch at full occupancy) past what the memory-side cache holds - measured: the mirror scene 18.8 -> 19.6 ms
+// per frame with two streams, where big-scene's share of an 8-way split gains 2.4 % and macho-cows 1.5 % (profiles/r05/c12_overlap.txt).
+// PORTRAYER_TWO_STREAMS=0 / 1 forces one / two.
+extern "C" void* pt_context_stream(pt_context* c, int slot) {
+    if (!c) return nullptr;
+    bool two = !(c->have_scene && c->needs_spill);
+    if (const char* e = getenv("PORTRAYER_TWO_STREAMS")) two = atoi(e) > 0;
+    return (void*)c->slot[two ? (slot & 1) : 0].stream;
+}
+extern "C" int pt_context_next_slot(const pt_context* c) { return c ? c->slot_next : 0; }
 
 // ------------------------------------------------------------------------------------------------
 // Scene upload
@@ -1175,31 +1198,31 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
         if (a.n_items > 2 && st != 1) { st = st % a.n_items; if (st < 1) st = 1; while (gcd(st, a.n_items) != 1) st++; a.item_stride = (uint32_t)st; }
     }
     int rc;
-    const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_STRIDE * sizeof(double) : 16;
-    if ((rc = pt_reserve(c, c->spill, spill_bytes))) return rc;
-    // + wave_rows: the wavefront's own stack takes LDS rows from the lanes' stacks (pt_wave_rows, pt_render_simple.h): eight, or what a deep tree needs
-    const int wave_rows = std::min(std::max(8, (a.scene.stack_cap + 63) / 64), std::max(a.stack_lds_cap, 8));  // (pt_wave_rows: at most this many)
-    const int stack_spill_entries = std::max(a.scene.stack_cap - a.stack_lds_cap + wave_rows, 0);
-    a.kd_sav_offset = (uint32_t)std::max(stack_spill_entries, a.scene.stack_cap);  // behind everything a lane's own stack can reach (pt_trace_wave gives the lanes fewer LDS rows in the k-d semantics)
-    if ((rc = pt_reserve(c, c->stack_spill, (size_t)a.n_lanes * ((size_t)a.kd_sav_offset + (kd_mode ? 2 * (size_t)std::max(a.scene.kd_levels, 0) : 0)) * 4))) return rc;
-    if ((rc = pt_reserve(c, c->misc, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4))) return rc;
-    if ((rc = pt_reserve(c, c->accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
-    a.accum = (double*)c->accum.p;
-    a.spill = (double*)c->spill.p;
-    a.stack_spill = (uint32_t*)c->stack_spill.p;
-    a.work_counter = (unsigned int*)c->misc.p;
-    a.overflow_flag = (unsigned int*)c->misc.p + 1;
-    a.counters = (PtCounters*)((char*)c->misc.p + 256);
-    a.work_queues = (unsigned int*)((char*)c->misc.p + 256 + sizeof(PtCounters));
-    c->last_mode = (uint32_t)a.scene.mode;
-    c->last_variant = (a.four_waves ? (uint32_t)a.four_waves : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4 || a.run_variant == PT_RUN_LINE5 || a.run_variant == PT_RUN_CHAIN) ? 0u : PT_KERNEL_INTERPRETER) | (a.run_variant == PT_RUN_CHAIN ? PT_KERNEL_CHAIN : 0u) |
-                      ((a.run_variant == PT_RUN_INTERP_PARK || a.run_variant == PT_RUN_INTERP_FORK) ? PT_KERNEL_PARK : 0u) | (a.run_variant == PT_RUN_INTERP_FORK ? PT_KERNEL_FORK : 0u) | (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
-    PT_HIP(c, hipMemsetAsync(c->misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
     if (slot_index < 0) {  // the host-buffer path (pt_render): one frame at a time
         if (c->slot[c->slot_oldest].pending) return pt_fail(c, PT_ERR_ARGUMENT, "a render is in flight: pt_render_finish first");
         slot_index = c->slot_next;
     }
-    pt_context::Slot& sl = c->slot[slot_index];
+    pt_context::Slot& sl = c->slot[slot_index];  // the launch's work buffers are its slot's: another frame may be in flight on the other slot's
+    const size_t spill_bytes = c->needs_spill ? (size_t)a.n_lanes * PT_SPILL_DEPTHS * PT_SPILL_STRIDE * sizeof(double) : 16;
+    if ((rc = pt_reserve(c, sl.spill, spill_bytes))) return rc;
+    // + wave_rows: the wavefront's own stack takes LDS rows from the lanes' stacks (pt_wave_rows, pt_render_simple.h): eight, or what a deep tree needs
+    const int wave_rows = std::min(std::max(8, (a.scene.stack_cap + 63) / 64), std::max(a.stack_lds_cap, 8));  // (pt_wave_rows: at most this many)
+    const int stack_spill_entries = std::max(a.scene.stack_cap - a.stack_lds_cap + wave_rows, 0);
+    a.kd_sav_offset = (uint32_t)std::max(stack_spill_entries, a.scene.stack_cap);  // behind everything a lane's own stack can reach (pt_trace_wave gives the lanes fewer LDS rows in the k-d semantics)
+    if ((rc = pt_reserve(c, sl.stack_spill, (size_t)a.n_lanes * ((size_t)a.kd_sav_offset + (kd_mode ? 2 * (size_t)std::max(a.scene.kd_levels, 0) : 0)) * 4))) return rc;
+    if ((rc = pt_reserve(c, sl.misc, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4))) return rc;
+    if ((rc = pt_reserve(c, sl.accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
+    a.accum = (double*)sl.accum.p;
+    a.spill = (double*)sl.spill.p;
+    a.stack_spill = (uint32_t*)sl.stack_spill.p;
+    a.work_counter = (unsigned int*)sl.misc.p;
+    a.overflow_flag = (unsigned int*)sl.misc.p + 1;
+    a.counters = (PtCounters*)((char*)sl.misc.p + 256);
+    a.work_queues = (unsigned int*)((char*)sl.misc.p + 256 + sizeof(PtCounters));
+    c->last_mode = (uint32_t)a.scene.mode;
+    c->last_variant = (a.four_waves ? (uint32_t)a.four_waves : 3u) | ((a.run_variant == PT_RUN_LINE3 || a.run_variant == PT_RUN_LINE4 || a.run_variant == PT_RUN_LINE5 || a.run_variant == PT_RUN_CHAIN) ? 0u : PT_KERNEL_INTERPRETER) | (a.run_variant == PT_RUN_CHAIN ? PT_KERNEL_CHAIN : 0u) |
+                      ((a.run_variant == PT_RUN_INTERP_PARK || a.run_variant == PT_RUN_INTERP_FORK) ? PT_KERNEL_PARK : 0u) | (a.run_variant == PT_RUN_INTERP_FORK ? PT_KERNEL_FORK : 0u) | (stats ? PT_KERNEL_COUNTING : 0u) | (tex ? PT_KERNEL_TEXTURED : 0u);
+    PT_HIP(c, hipMemsetAsync(sl.misc.p, 0, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4, stream));
     sl.mode = c->last_mode; sl.variant = c->last_variant; sl.counted = stats;
     PT_HIP(c, hipEventRecord(sl.ev0, stream));
     if (a.n_items) {
@@ -1209,7 +1232,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     }
     PT_HIP(c, hipEventRecord(sl.ev1, stream));
     // the overflow flag (always) and the counters (counting build) follow the kernels into the slot's pinned page
-    PT_HIP(c, hipMemcpyAsync(sl.host, c->misc.p, stats ? PT_SLOT_BYTES : 8, hipMemcpyDeviceToHost, stream));
+    PT_HIP(c, hipMemcpyAsync(sl.host, sl.misc.p, stats ? PT_SLOT_BYTES : 8, hipMemcpyDeviceToHost, stream));
     PT_HIP(c, hipEventRecord(sl.copy_done, stream));
     return PT_OK;
 }

@@ -130,6 +130,8 @@ struct pt_node {
     uint64_t frame_begun = 0, frame_ended = 0;  // frames begun / closed (begun - ended <= PT_NODE_FRAMES)
     uint64_t frame_used[PT_NODE_FRAMES] = {0, 0};  // how often a buffer set has been used (its `gathered` events are valid from the first use on)
     int fail_after_launch = -1;  // PORTRAYER_NODE_FAIL_AFTER_LAUNCH=<rank> (tests): see pt_node_frame_begin
+    bool one_stream = false;     // PORTRAYER_NODE_ONE_STREAM=1: see pt_node_frame_begin
+    std::vector<double> rank_kernel_ms;    // of the last frame closed: every rank's kernel time (HIP events around its launches)
     double host_ms[5] = {0, 0, 0, 0, 0};   // of the last frame: begin (launches + gather queued), wait (blocked until the image is complete), finish (flags, counters), per-rank launch (the slowest), the ranks' kernel times added up
 };
 
@@ -188,6 +190,7 @@ extern "C" int pt_node_create(int n_devices, const int* devices, pt_node** out) 
     bool threads = ranks > 1;
     if (const char* e = getenv("PORTRAYER_NODE_THREADS")) threads = atoi(e) > 0;
     if (const char* e = getenv("PORTRAYER_NODE_FAIL_AFTER_LAUNCH")) n->fail_after_launch = atoi(e);
+    if (const char* e = getenv("PORTRAYER_NODE_ONE_STREAM")) n->one_stream = atoi(e) > 0;
     if (threads) {
         n->worker.assign(ranks, nullptr);
         for (size_t r = 0; r < ranks; r++) { n->worker[r] = new RankWorker(); n->worker[r]->start(); }
@@ -213,6 +216,7 @@ extern "C" void pt_node_destroy(pt_node* n) {
     for (size_t r = 0; r < n->devices.size(); r++) {
         hipSetDevice(n->devices[r]);
         if (r < n->stream.size() && n->stream[r]) hipStreamSynchronize(n->stream[r]);
+        if (r < n->ctx.size() && n->ctx[r]) for (int k = 0; k < 2; k++) hipStreamSynchronize((hipStream_t)pt_context_stream(n->ctx[r], k));
         if (r < n->gstream.size() && n->gstream[r]) hipStreamSynchronize(n->gstream[r]);
         if (r < n->comm.size() && n->comm[r]) g_rccl.CommDestroy(n->comm[r]);
         if (r < n->d_bg.size() && n->d_bg[r]) hipFree(n->d_bg[r]);
@@ -294,6 +298,7 @@ static void node_drain(pt_node* n) {
     for (size_t r = 0; r < n->ctx.size(); r++) {
         hipSetDevice(n->devices[r]);
         hipStreamSynchronize(n->stream[r]);
+        for (int k = 0; k < 2; k++) hipStreamSynchronize((hipStream_t)pt_context_stream(n->ctx[r], k));
         hipStreamSynchronize(n->gstream[r]);
         for (int k = 0; k < 4 && pt_render_finish(n->ctx[r], nullptr) != PT_ERR_ARGUMENT; k++) { }  // PT_ERR_ARGUMENT: nothing in flight
     }
@@ -334,13 +339,16 @@ extern "C" int pt_node_frame_begin(pt_node* n, const pt_camera* camera, const pt
         const auto l0 = std::chrono::steady_clock::now();
         int rr = PT_OK;
         hipError_t e = hipSetDevice(n->devices[r]);
-        if (e == hipSuccess && reuse) e = hipStreamWaitEvent(n->stream[r], n->gathered[f][r], 0);
+        // The frame renders on the stream of the context slot it takes: two open frames are on two queues, and the wavefronts of frame k + 1 start in the
+        // places frame k's tail frees (pt_context::Slot, csrc/pt_api.hip; PORTRAYER_NODE_ONE_STREAM=1 keeps every frame on the rank's one stream, for A/B runs)
+        hipStream_t rs = n->one_stream ? n->stream[r] : (hipStream_t)pt_context_stream(n->ctx[r], pt_context_next_slot(n->ctx[r]));
+        if (e == hipSuccess && reuse) e = hipStreamWaitEvent(rs, n->gathered[f][r], 0);
         if (e == hipSuccess) {
             pt_render_params q = p;
             q.tile_rank = r;
-            rr = pt_render_device(n->ctx[r], camera, (const double*)n->d_bg[r], &q, 1, n->d_compact[f][r], n->stream[r]);
+            rr = pt_render_device(n->ctx[r], camera, (const double*)n->d_bg[r], &q, 1, n->d_compact[f][r], rs);
             if (rr == PT_OK) {
-                e = hipEventRecord(n->done[f][r], n->stream[r]);
+                e = hipEventRecord(n->done[f][r], rs);
                 if (e == hipSuccess) e = hipStreamWaitEvent(n->gstream[r], n->done[f][r], 0);
                 if (e != hipSuccess) { rr = PT_ERR_DEVICE; hip_after_launch[r] = std::string("a HIP call behind its launch failed: ") + hipGetErrorString(e); }  // launched: still to be closed
             }
@@ -431,6 +439,8 @@ extern "C" int pt_node_frame_end(pt_node* n, pt_stats* stats) {
         total.n_analytic += st.n_analytic; total.n_tri += st.n_tri; total.n_bbox += st.n_bbox; total.kd_plane_miss += st.kd_plane_miss;
         total.stack_overflow += st.stack_overflow;
         for (int k = 0; k < 8; k++) total.diag[k] += st.diag[k];
+        if (n->rank_kernel_ms.size() != ranks) n->rank_kernel_ms.assign(ranks, 0.0);
+        n->rank_kernel_ms[r] = st.kernel_ms;
         if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms;  // the slowest rank's kernel
         total.total_ms += st.kernel_ms;                                     // (moved to host_ms[4] below) the ranks' kernel times added up
         total.kernel_mode = st.kernel_mode; total.kernel_variant = st.kernel_variant;
@@ -455,6 +465,14 @@ extern "C" int pt_node_frames_in_flight(const pt_node* n) { return n ? (int)(n->
 extern "C" int pt_node_last_frame_host_ms(const pt_node* n, double out[5]) {
     if (!n || !out) return PT_ERR_ARGUMENT;
     for (int k = 0; k < 5; k++) out[k] = n->host_ms[k];
+    return PT_OK;
+}
+
+// Every rank's kernel time of the last frame closed (milliseconds, HIP events around the rank's launches). With two frames open the second frame's
+// launch shares the GPU with the first one's tail, so its figure covers both: time one frame at a time for a rank's own cost.
+extern "C" int pt_node_last_frame_rank_kernel_ms(const pt_node* n, double* out, int n_out) {
+    if (!n || !out || n_out < 0) return PT_ERR_ARGUMENT;
+    for (int r = 0; r < n_out; r++) out[r] = (size_t)r < n->rank_kernel_ms.size() ? n->rank_kernel_ms[r] : 0.0;
     return PT_OK;
 }
 

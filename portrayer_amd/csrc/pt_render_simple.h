@@ -184,6 +184,10 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
     if (STATS) memset(&cnt, 0, sizeof cnt);
     unsigned q_next = 0, q_end = 0, q_seen = 0;  // the wavefront's private batch of items (wave-uniform), as in pt_render_kernel
     if (a.fine_queues) q_next = blockIdx.x % a.fine_queues;
+#ifdef PT_TIMELINE  // profiles/timeline.sh: when wavefronts start and end, and how long the longest item takes (100 MHz ticks), as in pt_render_kernel
+    const unsigned long long tl_start = wall_clock64();
+    unsigned long long tl_item_max = 0, tl_first_item = 0;
+#endif
 
     for (;;) {
         unsigned w;
@@ -213,6 +217,10 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
             if (w == 0xFFFFFFFFu) break;
         }
 
+#ifdef PT_TIMELINE
+        const unsigned long long tl_item = wall_clock64();
+        if (!tl_first_item) tl_first_item = tl_item;
+#endif
 #ifdef PT_CYCLES  // sections of an item outside the walks: diag[3] primary ray, diag[4] surface of the hit, diag[6] light + shadow ray set-up, diag[7] light term
         const unsigned long long cyc_item0 = __builtin_readcyclecounter();
         unsigned long long sec_t0 = cyc_item0;
@@ -409,6 +417,21 @@ __global__ void __launch_bounds__(PT_BLOCK, WAVES) pt_render_simple_kernel(PtRen
 #ifdef PT_CYCLES  // the whole item -> diag[2] (the part outside the walks = diag[2] - diag[0])
         if (STATS && lane == 0) cnt.diag[2] += __builtin_readcyclecounter() - cyc_item0;
 #endif
+#ifdef PT_TIMELINE
+        { const unsigned long long d = wall_clock64() - tl_item; if (d > tl_item_max) tl_item_max = d; }
+#endif
     }
+#ifdef PT_TIMELINE
+    if (STATS && lane == 0) {
+        const unsigned long long tl_end = wall_clock64();
+        cnt.diag[0] = tl_end - tl_start; cnt.diag[1] = 1;                       // summed: wavefront lifetimes, wavefronts
+        atomicMax(&a0.counters->diag[2], tl_item_max);                            // longest item
+        atomicMax(&a0.counters->diag[4], ~tl_start);                              // ~(earliest start)
+        atomicMax(&a0.counters->diag[5], tl_end);                                 // latest end
+        cnt.diag[3] = tl_first_item ? tl_first_item - tl_start : 0;               // summed: start -> first item in hand
+        atomicMax(&a0.counters->diag[6], ~tl_end);                                // ~(earliest end): the tail is latest end - earliest end
+        cnt.diag[2] = cnt.diag[4] = cnt.diag[5] = cnt.diag[6] = 0;
+    }
+#endif
     if (STATS) pt_flush_counters(a.counters, cnt);
 }

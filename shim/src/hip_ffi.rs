@@ -1,4 +1,4 @@
-//! Declarations of the C ABI in include/portrayer_hip.h (PT_ABI_VERSION 7), field for field.
+//! Declarations of the C ABI in include/portrayer_hip.h (PT_ABI_VERSION 8), field for field.
 //! tests/test_integration_doc.py of the MI355X repository checks these structs against the header.
 #![allow(dead_code)]
 
@@ -7,7 +7,7 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct PtContext { _private: [u8; 0] }
 #[repr(C)] pub struct PtNode { _private: [u8; 0] }
 
-pub const PT_ABI_VERSION: c_int = 7;
+pub const PT_ABI_VERSION: c_int = 8;
 
 // enum Primitive, src/primitive.rs:67-81
 pub const PT_PRIM_SPHERE: i32 = 0;
@@ -97,6 +97,8 @@ extern "C" {
     pub fn pt_render_device(ctx: *mut PtContext, camera: *const PtCamera, d_background: *const f64, params: *const PtRenderParams,
                             compact: c_int, d_rgb: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn pt_render_finish(ctx: *mut PtContext, stats: *mut PtStats) -> c_int;
+    pub fn pt_context_stream(ctx: *mut PtContext, slot: c_int) -> *mut c_void;
+    pub fn pt_context_next_slot(ctx: *const PtContext) -> c_int;
     // one render call over the GPUs of a node (one context per GPU, one RCCL gather)
     pub fn pt_node_create(n_devices: c_int, devices: *const c_int, out: *mut *mut PtNode) -> c_int;
     pub fn pt_node_destroy(node: *mut PtNode);

@@ -245,6 +245,67 @@ def test_node_frames_in_a_pipeline(H, monkeypatch, ranks, threads):
     lib.pt_node_destroy(node)
 
 
+@pytest.mark.parametrize("scene_name,traverse", [("macho-cows", "flat"), ("entering-the-mirror-dimension", "kd"), ("transmission-refraction", "flat")])
+@pytest.mark.parametrize("two", ["0", "1"])
+def test_two_frames_in_flight_on_two_streams_of_one_context(H, monkeypatch, scene_name, traverse, two):
+    """ABI 8: the two renders a context may have in flight own their work buffers (chunk sums, recursion frames, stack columns, counters, work queues) and
+    may run on the context's two streams at once - the next frame's persistent wavefronts start where this frame's tail frees places. Frames with DIFFERENT
+    cameras and sample seeds, alternating slots, the older frame closed after the newer one is queued: every image and every frame's own ray counts == the
+    same render done alone (straight-line, chain and interpreter kernels: the last two park recursion frames in the slot's HBM lines)."""
+    import device_glue
+    from example_scenes import EXAMPLES, TEXTURED_EXAMPLES
+    from scene_dsl import Camera
+    scene, cam0 = (TEXTURED_EXAMPLES if scene_name in TEXTURED_EXAMPLES else EXAMPLES)[scene_name]()[:2]
+    tr = H.TRAVERSE_KD if traverse == "kd" else H.TRAVERSE_FLAT
+    if two == "1":  # two streams forced for every scene: the recursion frames of two launches must not meet either
+        monkeypatch.setenv("PORTRAYER_TWO_STREAMS", "1")
+    cams = [cam0] + [Camera(eye=(cam0.eye[0] + 0.4 * k, cam0.eye[1] + 0.2 * k, cam0.eye[2] - 0.3 * k), center=cam0.center, up=cam0.up, fovy_degrees=cam0.fovy_degrees) for k in (1, 2, 3, 4, 5)]
+    ds = device_glue.DeviceScene(scene, tr)
+    lib = H.lib()
+    w, h, samples = 160, 96, 4
+    bg = default_background(w, h)
+    ctx = H.Context()
+    ds.upload(ctx)
+    alone = [device_glue.render(ctx, cam, w, h, samples=samples, seed=10 + k, sample_mode=H.SAMPLE_RNG, stats=True) for k, cam in enumerate(cams)]
+    c = ctx._h
+    d_bg = C.c_void_p()
+    assert lib.pt_device_alloc(c, bg.nbytes, C.byref(d_bg)) == 0
+    assert lib.pt_copy_to_device(c, d_bg, bg.ctypes.data_as(C.c_void_p), bg.nbytes) == 0
+    d_img = [C.c_void_p(), C.c_void_p()]
+    for d in d_img:
+        assert lib.pt_device_alloc(c, w * h * 3, C.byref(d)) == 0
+    # two streams where the scene's kernels keep no recursion frames in HBM, one for both slots where they do (csrc/pt_api.hip: pt_context_stream)
+    assert lib.pt_context_stream(c, 0) and lib.pt_context_stream(c, 1)
+    assert (lib.pt_context_stream(c, 0) != lib.pt_context_stream(c, 1)) == (scene_name == "macho-cows" or two == "1")
+    got, slots = [], []
+    st = H.PtStats()
+
+    def close(k):  # the OLDEST open frame is frame k: its image is in the buffer of the slot it took
+        assert lib.pt_render_finish(c, C.byref(st)) == 0, lib.pt_last_error(c)
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        assert lib.pt_copy_from_device(c, img.ctypes.data_as(C.c_void_p), d_img[slots[k]], img.nbytes) == 0
+        got.append((img, st.as_dict()))
+
+    for k, cam in enumerate(cams):
+        slot = int(lib.pt_context_next_slot(c))
+        slots.append(slot)
+        p = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), samples, 10 + k, H.SAMPLE_RNG, 1, 0, 1, 1)
+        camera = device_glue.camera_struct(cam, w, h)
+        assert lib.pt_render_device(c, C.byref(camera), d_bg, C.byref(p), 0, d_img[slot], C.c_void_p(lib.pt_context_stream(c, slot))) == 0, lib.pt_last_error(c)
+        if k > 0:
+            close(k - 1)
+    close(len(cams) - 1)
+    assert slots == [0, 1, 0, 1, 0, 1]
+    p = H.PtRenderParams(w, h, H.PtRect(0, 0, w - 1, h - 1), samples, 10, H.SAMPLE_RNG, 1, 0, 1, 1)
+    for k, ((img, stk), (ref_img, _, ref_st)) in enumerate(zip(got, alone)):
+        assert np.array_equal(img, ref_img), f"frame {k} differs from the same render done alone"
+        for key in ("primary", "shadow", "reflect", "refract", "hits"):
+            assert stk[key] == ref_st[key], (k, key)
+    for d in d_img + [d_bg]:
+        lib.pt_device_free(c, d)
+    ctx.close()
+
+
 def test_node_failure_behind_a_launch_and_uploads_under_open_frames(H, monkeypatch):
     """(1) a HIP call that fails BEHIND a rank's launch must come back as one of the header's negative codes with its own
     text (the old sentinel PT_ERR_DEVICE + 1000 = 998 was positive and never recognised), the launches that did go out closed, and the

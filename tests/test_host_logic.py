@@ -37,7 +37,7 @@ def test_libraries_export_every_declared_symbol():
     for f in host_fns:
         getattr(host.lib(), f)
     import __graft_entry__
-    assert _hip.lib().pt_abi_version() == __graft_entry__.header_abi_version() == 7
+    assert _hip.lib().pt_abi_version() == __graft_entry__.header_abi_version() == 8
 
 
 def test_driver_build_entry_point_passes():
