@@ -1173,6 +1173,9 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     lds_cap = std::max(lds_cap, 2);
     if (const char* e = getenv("PORTRAYER_LDS_STACK")) lds_cap = std::max(1, atoi(e));  // experiments / tests of the overflow path
     a.stack_lds_cap = std::min(lds_cap, a.scene.stack_cap);
+    // the k-d walk keeps no saved bounds in HBM any more (round 5): its wavefront rows must hold the stack and, where the stack's slack is too small for it, the
+    // two rows of the path table (pt_kd_layout, PtKdSav) - also under PORTRAYER_LDS_STACK=1, which then only shrinks the LANES' stacks
+    if (kd_sem) a.stack_lds_cap = std::max(a.stack_lds_cap, (a.scene.stack_cap + 63) / 64 + 2);
     uint32_t grid = 0;
     PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
@@ -1187,7 +1190,6 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // are 1 % better off with batches.
     const uint64_t resident_waves = (uint64_t)grid * (PT_BLOCK / 64);
     const bool long_launch = (uint64_t)a.n_items > 2048ull * std::max<uint64_t>(resident_waves, 1);
-    const bool kd_mode = a.scene.mode == PT_MODE_KD || a.scene.mode == PT_MODE_KD_NOMESH || a.scene.mode == PT_MODE_KD_MESH;
     // (round 3's per-lane k-d walk was 1 % better off with batches; the wave-uniform one is not: big-scene +1.1 %, macho-cows +3.2 % with the queues, round 4 c68)
     a.fine_queues = (c->spawns || !long_launch) ? 16 : 0;  // 8 .. 32 queues measured alike, 64 and 4 about 1 % behind
     if (const char* e = getenv("PORTRAYER_FINE_QUEUES")) a.fine_queues = (uint32_t)std::max(0, std::min(PT_FINE_QUEUES, atoi(e)));
@@ -1209,7 +1211,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     const int wave_rows = std::min(std::max(8, (a.scene.stack_cap + 63) / 64), std::max(a.stack_lds_cap, 8));  // (pt_wave_rows: at most this many)
     const int stack_spill_entries = std::max(a.scene.stack_cap - a.stack_lds_cap + wave_rows, 0);
     a.kd_sav_offset = (uint32_t)std::max(stack_spill_entries, a.scene.stack_cap);  // behind everything a lane's own stack can reach (pt_trace_wave gives the lanes fewer LDS rows in the k-d semantics)
-    if ((rc = pt_reserve(c, sl.stack_spill, (size_t)a.n_lanes * ((size_t)a.kd_sav_offset + (kd_mode ? 2 * (size_t)std::max(a.scene.kd_levels, 0) : 0)) * 4))) return rc;
+    if ((rc = pt_reserve(c, sl.stack_spill, (size_t)a.n_lanes * (size_t)a.kd_sav_offset * 4))) return rc;  // (the k-d walk's saved bounds needed columns behind this until round 5)
     if ((rc = pt_reserve(c, sl.misc, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4))) return rc;
     if ((rc = pt_reserve(c, sl.accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
     a.accum = (double*)sl.accum.p;

@@ -67,7 +67,7 @@ PT_HD int pt_wave_rows(const PtRenderArgs& a) {
 // of per-lane stack columns - only scenes with KDMesh trees have any (pt_kdmesh_hit) -, then per wavefront `wrows` rows of 64 words:
 // `srows` for its stack (a word per pending split + what a mesh's triangle tree can have pending), the rest two rows per tree level for
 // the lanes' saved range bounds - the deepest levels; the top ones, touched once or twice per ray, in the lanes' HBM columns.
-struct PtKdLayout { int lane_rows, wrows, srows, lds_levels; };
+struct PtKdLayout { int lane_rows, wrows, srows, lds_levels, path_word; };  // path_word: where in the wavefront's region the path table starts (words)
 template <int MODE>
 PT_HD PtKdLayout pt_kd_layout(const PtRenderArgs& a) {
     PtKdLayout l;
@@ -81,8 +81,23 @@ PT_HD PtKdLayout pt_kd_layout(const PtRenderArgs& a) {
         l.lane_rows = r < 0 ? 0 : r;
     }
     l.wrows = cap - l.lane_rows;  // >= 1
+    if (l.wrows < l.srows + 2 && 3 * a.scene.kd_levels > l.srows * 64 - a.scene.stack_cap) {  // room for the path table comes first (pt_render_common keeps cap >= srows + 2 in these semantics)
+        l.wrows = cap < l.srows + 2 ? cap : l.srows + 2;
+        l.lane_rows = cap - l.wrows;
+    }
+    // the levels that get no slot are recomputed from the path table (PtKdSav, pt_trace.h): 3 words per such level, in the slack behind the wavefront's stack
+    // (its rows hold srows x 64 words, the walks need scene.stack_cap of them) or, where that is too small, in two rows taken from the level slots
     int lv = (l.wrows - l.srows) / 2;
-    l.lds_levels = lv < 0 ? 0 : (lv > a.scene.kd_levels ? a.scene.kd_levels : lv);
+    lv = lv < 0 ? 0 : (lv > a.scene.kd_levels ? a.scene.kd_levels : lv);
+    const int slack = l.srows * 64 - a.scene.stack_cap;
+    if (3 * (a.scene.kd_levels - lv) <= slack && l.wrows >= l.srows) {
+        l.path_word = a.scene.stack_cap;
+    } else {  // (3 x 32 levels = 96 words: two rows always do)
+        lv = (l.wrows - l.srows - 2) / 2;
+        lv = lv < 0 ? 0 : (lv > a.scene.kd_levels ? a.scene.kd_levels : lv);
+        l.path_word = (l.srows + 2 * lv) * 64;
+    }
+    l.lds_levels = lv;
     return l;
 }
 
@@ -124,10 +139,11 @@ PT_HD void pt_trace_wave(const PtRenderArgs& a, const PtRay& ray, bool tracing, 
         uint32_t* wbase = lds + (size_t)lane_rows * PT_BLOCK + (size_t)wave * wrows * 64;
         PtKdSav sav;
         sav.lds = wbase + (size_t)srows * 64;
-        sav.hbm_levels = a.scene.kd_levels - lds_levels;
-        sav.hbm = stk.gbase + (size_t)a.kd_sav_offset * stk.gstride;
-        sav.hbm_stride = stk.gstride;
-        pt_trace_packet_kd<STATS, MODE == PT_MODE_KD || MODE == PT_MODE_KD_MESH, MODE == PT_MODE_KD>(a.scene, ray, tracing, any, hit, wbase, (wrows < srows ? wrows : srows) * 64, sav, lane_stk, a.overflow_flag, cnt);
+        sav.top_levels = a.scene.kd_levels - lds_levels;
+        sav.path = wbase + kl.path_word;
+        int stack_words = (wrows < srows ? wrows : srows) * 64;
+        if (kl.path_word < stack_words) stack_words = kl.path_word;  // (the path table sits in the slack of the stack's rows: the stack ends where it begins)
+        pt_trace_packet_kd<STATS, MODE == PT_MODE_KD || MODE == PT_MODE_KD_MESH, MODE == PT_MODE_KD>(a.scene, ray, tracing, any, hit, wbase, stack_words, sav, lane_stk, a.overflow_flag, cnt);
     }
 #else
     if (tracing) pt_trace<MODE, STATS>(a.scene, ray, any, hit, stk, cnt);

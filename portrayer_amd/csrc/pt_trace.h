@@ -1771,31 +1771,28 @@ PT_HD pt_u32x16 pt_sload16_off(const void* base, uint32_t byte_off) {
 
 // (pt_rcp_refined / pt_div_exp_ok / pt_div_fast - the short f64 division by a repeated denominator - live in pt_math.h)
 
+// The lanes' replaced range bounds per tree level (see pt_trace_packet_kd). Round 5: only the DEEP levels keep a slot (in LDS); a bound replaced at one of
+// the `top_levels` levels nearest the root is not stored at all - it is recomputed when the walk comes back to that level:
+//   at any node, a lane's `end` is the plane parameter of the DEEPEST level above it whose code says "straddled, now in the near child" (code 2), or
+//   infinity; its `start` is that of the deepest level with code 3 ("straddled, now in the far child"), or epsilon - the codes (two bits per level, in a
+//   register) and the planes of the current path determine the range completely. The path is the same for every lane of the wavefront, so the planes of
+//   its top levels sit in a small table in the wavefront's LDS (`path`: plane lo, plane hi, axis per level), and a plane parameter is recomputed with the very
+//   expression that produced it, (plane - o) / d: the same bits.
+// (Round 4 stored the top levels' bounds in the lanes' HBM columns: 16 bytes per lane, level and ray written and read back - 30 GB per big-scene frame.)
 struct PtKdSav {
-    uint32_t* lds;        // the wavefront's rows for saved bounds: slot j, half h of lane l at lds[(2 j + h) * 64 + l]
-    int hbm_levels;       // levels [0, hbm_levels) live in HBM, level k >= hbm_levels in LDS slot k - hbm_levels
-    uint32_t* hbm;        // this lane's column: half h of level k at hbm[(2 k + h) * hbm_stride]
-    uint32_t hbm_stride;
+    uint32_t* lds;        // the wavefront's rows for saved bounds: level k >= top_levels in slot k - top_levels; slot j, half h of lane l at lds[(2 j + h) * 64 + l]
+    int top_levels;       // levels [0, top_levels) keep no slot: recomputed from `path`
+    uint32_t* path;       // the wavefront's table of the current path's top levels: path[3 k] / [3 k + 1] the plane (f64 halves), path[3 k + 2] the axis
 };
-PT_HD void pt_kd_sav_store(const PtKdSav& s, int level, double v) {  // `level` is wave-uniform
+PT_HD void pt_kd_sav_store(const PtKdSav& s, int level, double v) {  // `level` is wave-uniform and >= s.top_levels
     union { double d; uint32_t u[2]; } c; c.d = v;
-    if (level >= s.hbm_levels) {
-        uint32_t* p = s.lds + (size_t)(2 * (level - s.hbm_levels)) * 64 + PT_LANE_ID();
-        p[0] = c.u[0]; p[64] = c.u[1];
-    } else {
-        uint32_t* p = s.hbm + (size_t)(2 * level) * s.hbm_stride;
-        p[0] = c.u[0]; p[s.hbm_stride] = c.u[1];
-    }
+    uint32_t* p = s.lds + (size_t)(2 * (level - s.top_levels)) * 64 + PT_LANE_ID();
+    p[0] = c.u[0]; p[64] = c.u[1];
 }
 PT_HD double pt_kd_sav_load(const PtKdSav& s, int level) {
     union { double d; uint32_t u[2]; } c;
-    if (level >= s.hbm_levels) {
-        const uint32_t* p = s.lds + (size_t)(2 * (level - s.hbm_levels)) * 64 + PT_LANE_ID();
-        c.u[0] = p[0]; c.u[1] = p[64];
-    } else {
-        const uint32_t* p = s.hbm + (size_t)(2 * level) * s.hbm_stride;
-        c.u[0] = p[0]; c.u[1] = p[s.hbm_stride];
-    }
+    const uint32_t* p = s.lds + (size_t)(2 * (level - s.top_levels)) * 64 + PT_LANE_ID();
+    c.u[0] = p[0]; c.u[1] = p[64];
     return c.d;
 }
 #ifndef PT_KD_WALK_STEPS_MAX
@@ -1877,6 +1874,15 @@ PT_HD void pt_kd_split_eval(double o, double d, double y, pt_mask d_ok, double p
         strad = cross & pt_in_range_m(start, end, plane_t);
     }
     *s_out = s; *e_out = e; *cross_out = cross; *strad_out = strad; *plane_t_out = plane_t;
+}
+
+// plane_t = (plane - o) / d of pt_kd_split_eval for the lanes in `who`, computed again (a pop at a top level: PtKdSav): the short division where every such
+// lane's operands are inside its window, else the hardware's - either way the quotient `/` gives, so the very bits the split produced.
+PT_HD double pt_kd_plane_t(double o, double d, double y, pt_mask d_ok, double plane, pt_mask who) {
+    const double n = plane - o;
+    const pt_mask fast = d_ok & pt_div_exp_ok_m(n);
+    if (who & PT_MNOT(fast)) return n / d;
+    return pt_div_fast(n, d, y);
 }
 
 // wstack: the wavefront's own stack (linear, `wwords` words); sav: the lanes' saved bounds per level; lane_stk: the lanes' own stacks
@@ -1974,7 +1980,9 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                 // read later may write it too.
                 const pt_mask near_first = front_first ? s : PT_MNOT(s);
                 const pt_mask both = (push && descend) ? strad : 0ull;
-                if (both) pt_kd_sav_store(sav, lev, PT_LANES(near_first) ? end : start);
+                if (lev < sav.top_levels) {  // a top level: no slot - the path table gets the split's plane and axis (every lane writes the same words)
+                    if (push && descend) { sav.path[3 * lev] = v[0]; sav.path[3 * lev + 1] = v[1]; sav.path[3 * lev + 2] = v[2]; }
+                } else if (both) pt_kd_sav_store(sav, lev, PT_LANES(near_first) ? end : start);
                 uint32_t code = PT_LANES((push && descend) ? in_second : 0ull) ? 1u : 0u;
                 code = PT_LANES(both & near_first) ? 2u : code;
                 code = PT_LANES(both & PT_MNOT(near_first)) ? 3u : code;
@@ -2084,20 +2092,22 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
         const uint32_t entry = PT_UNIFORM_U32(wstack[sp]);
         cur = entry >> 5;
         const int L = (int)(entry & 31u);
-        for (int k = lev - 1; k > L; k--) {  // the finished levels below it: put the replaced bounds back
-            const uint32_t c = ((k < 16 ? codes_lo : codes_hi) >> (2 * (k & 15))) & 3u;
-            const pt_mask c2m = PT_U32_EQ(c, 2u), c3m = PT_U32_EQ(c, 3u);
-            if (c2m | c3m) {
-                const double sv = pt_kd_sav_load(sav, k);  // (lanes whose slot holds nothing read it too: not used)
-                end = PT_LANES(c2m) ? sv : end;
-                start = PT_LANES(c3m) ? sv : start;
+        if (L >= sav.top_levels) {
+            for (int k = lev - 1; k > L; k--) {  // the finished levels below it: put the replaced bounds back
+                const uint32_t c = ((k < 16 ? codes_lo : codes_hi) >> (2 * (k & 15))) & 3u;
+                const pt_mask c2m = PT_U32_EQ(c, 2u), c3m = PT_U32_EQ(c, 3u);
+                if (c2m | c3m) {
+                    const double sv = pt_kd_sav_load(sav, k);  // (lanes whose slot holds nothing read it too: not used)
+                    end = PT_LANES(c2m) ? sv : end;
+                    start = PT_LANES(c3m) ? sv : start;
+                }
             }
         }
         {
             const int sh = 2 * (L & 15);
             const uint32_t c = ((L < 16 ? codes_lo : codes_hi) >> sh) & 3u;
             const pt_mask c2m = PT_U32_EQ(c, 2u), c3m = PT_U32_EQ(c, 3u);
-            if (c2m | c3m) {
+            if (L >= sav.top_levels && (c2m | c3m)) {
                 // had [start, plane_t) (c == 2, the slot holds the end): now [plane_t, end), the slot keeps the start for the way back up;
                 // had [plane_t, end) (c == 3, the slot holds the start): now [start, plane_t), the slot keeps the end
                 const double sv = pt_kd_sav_load(sav, L);
@@ -2110,6 +2120,27 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
             const uint32_t c2 = PT_LANES(c2m) ? 3u : (PT_LANES(c3m) ? 2u : 0u);
             if (L < 16) codes_lo = (codes_lo & ~(3u << sh)) | (c2 << sh);
             else codes_hi = (codes_hi & ~(3u << sh)) | (c2 << sh);
+        }
+        if (L < sav.top_levels && !done) {
+            // A top level: the range of the second child from the codes of the levels 0 .. L alone (see PtKdSav) - end = the plane parameter of the deepest
+            // level with code 2, else infinity; start = that of the deepest level with code 3, else epsilon. Deepest first, until every lane has both.
+            pt_mask need_e = in, need_s = in;
+            for (int j = L; j >= 0 && (need_e | need_s); j--) {
+                const uint32_t cj = ((j < 16 ? codes_lo : codes_hi) >> (2 * (j & 15))) & 3u;
+                const pt_mask e_here = PT_U32_EQ(cj, 2u) & need_e, s_here = PT_U32_EQ(cj, 3u) & need_s;
+                if (!(e_here | s_here)) continue;
+                const uint32_t p0 = PT_UNIFORM_U32(sav.path[3 * j]), p1 = PT_UNIFORM_U32(sav.path[3 * j + 1]), ax = PT_UNIFORM_U32(sav.path[3 * j + 2]);
+                const double plane = pt_f64_of(p0, p1);
+                double tj;
+                if (ax == 0u) tj = pt_kd_plane_t(ray.o.x, ray.d.x, yx, okx, plane, e_here | s_here);
+                else if (ax == 1u) tj = pt_kd_plane_t(ray.o.y, ray.d.y, yy, oky, plane, e_here | s_here);
+                else tj = pt_kd_plane_t(ray.o.z, ray.d.z, yz, okz, plane, e_here | s_here);
+                end = PT_LANES(e_here) ? tj : end;
+                start = PT_LANES(s_here) ? tj : start;
+                need_e &= PT_MNOT(e_here); need_s &= PT_MNOT(s_here);
+            }
+            end = PT_LANES(need_e) ? (double)INFINITY : end;
+            start = PT_LANES(need_s) ? (double)PT_EPSILON : start;
         }
         lev = L + 1;
         if (done) break;
