@@ -137,7 +137,7 @@ static int sphere_hit(const ray_t *ray, const po_range *range, hit_t *out) { /* 
     /* sphere.rs:53-96 */
     const double PI = 3.14159265358979323846;
     po_vec3 p = out->p, normal = out->p;
-    out->has_uv = 1;
+    out->has_uv = 2; /* (2: from atan2 / acos - texel_at counts how close such coordinates come to a texel edge) */
     out->u = (PI + atan2(-p.z, p.x)) / (2.0 * PI);
     out->v = acos(p.y) / PI;
     po_vec3 to_top = po_normalized(po_sub(po_v3(0.0, 1.0, 0.0), p));
@@ -780,9 +780,15 @@ static inline double powi5(double x) { /* f64::powi(5) = llvm.powi: x * ((x*x)*(
 }
 
 /* texture.rs:96-141 RgbImageBuffer::at: nearest texel, wrap-around; channels as f64 / 255 */
-static po_vec3 texel_at(const po_scene *sc, int32_t tex, double u, double v) {
+static int near_integer(double f) { /* within PO_TEX_EDGE_ULPS units in the last place of f of an integer (the truncation below changes there) */
+    if (f != f || fabs(f) >= 4503599627370496.0) return 0;
+    double r = nearbyint(f), ulp = nextafter(fabs(f) > 1.0 ? fabs(f) : 1.0, INFINITY) - (fabs(f) > 1.0 ? fabs(f) : 1.0);
+    return fabs(f - r) <= PO_TEX_EDGE_ULPS * ulp;
+}
+static po_vec3 texel_at(const po_scene *sc, int32_t tex, double u, double v, int from_sphere, po_stats *st) {
     int64_t width = sc->texture_size[2 * tex], height = sc->texture_size[2 * tex + 1];
     double fx = u * (double)(width - 1), fy = v * (double)(height - 1);
+    if (from_sphere) { st->tex_sphere_lookups++; if (near_integer(fx) || near_integer(fy)) st->tex_sphere_near_edge++; }
     /* Rust `as i64`: truncation toward zero, saturating, NaN -> 0 */
     int64_t x = fx != fx ? 0 : (fx >= 9.2233720368547758e18 ? INT64_MAX : (fx <= -9.2233720368547758e18 ? INT64_MIN : (int64_t)fx));
     int64_t y = fy != fy ? 0 : (fy >= 9.2233720368547758e18 ? INT64_MAX : (fy <= -9.2233720368547758e18 ? INT64_MIN : (int64_t)fy));
@@ -816,7 +822,7 @@ static po_vec3 hit_color(const ctx_t *cx, int32_t mat_id, po_vec3 bg, po_vec3 ra
         normal = po_normalized(normal_raw); /* material.rs:123-125 */
     } else { /* material.rs:126-136 + texture.rs:192-221; quirk Q12: the TBN is the primitive's model-space one */
         if (!hit->has_uv || !hit->has_tbn) { st->kd_plane_miss += 1u << 20; return bg; } /* the reference panics */
-        po_vec3 tn = texel_at(sc, nmap, tu, tv);
+        po_vec3 tn = texel_at(sc, nmap, tu, tv, hit->has_uv == 2, st);
         po_vec3 norm = po_v3(2.0 * tn.x - 1.0, 2.0 * tn.y - 1.0, -(2.0 * tn.z - 1.0));
         po_mat3 to_rh = {{{1, 0, 0}, {0, 0, -1}, {0, -1, 0}}};
         po_vec3 tex_norm = mat3_mul(&to_rh, norm);
@@ -824,7 +830,7 @@ static po_vec3 hit_color(const ctx_t *cx, int32_t mat_id, po_vec3 bg, po_vec3 ra
     }
     if (tex >= 0) { /* material.rs:138-144, texture.rs:162-168: sRGB -> linear with powf(2.2) */
         if (!hit->has_uv) { st->kd_plane_miss += 1u << 20; return bg; } /* the reference panics */
-        po_vec3 c = texel_at(sc, tex, tu, tv);
+        po_vec3 c = texel_at(sc, tex, tu, tv, hit->has_uv == 2, st);
         kd = po_v3(pow(c.x, PO_GAMMA), pow(c.y, PO_GAMMA), pow(c.z, PO_GAMMA));
     }
     po_vec3 color = po_mul(po_v3(sc->ambient[0], sc->ambient[1], sc->ambient[2]), kd); /* :148 */

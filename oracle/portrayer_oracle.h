@@ -83,7 +83,13 @@ typedef struct {
     uint64_t n_tri;                             /* triangle tests */
     uint64_t n_bbox;                            /* mesh bounding-box tests */
     uint64_t kd_plane_miss;                     /* node.rs:146-147,177-178 would have panicked */
+    /* Round 5. A sphere's texture coordinates go through libm's atan2 / acos (sphere.rs:59-96); the device's routines are within 2 / 1 ulp of
+     * glibc's, not bit-equal. A texel can only differ when u (w - 1) or v (h - 1) lies that close to an integer: these two counters let a test PROVE that no
+     * lookup of a render did - tex_sphere_lookups counts the texel fetches (texture.rs:96-141) whose coordinates came from a sphere hit, tex_sphere_near_edge
+     * those of them with a scaled coordinate within PO_TEX_EDGE_ULPS units in the last place of an integer. */
+    uint64_t tex_sphere_lookups, tex_sphere_near_edge;
 } po_stats;
+#define PO_TEX_EDGE_ULPS 4096.0
 
 typedef struct {
     uint32_t width, height;

@@ -77,7 +77,9 @@ def run(first, count, w=128, h=96, samples=2, modes=None, out=print):
                 if kind != "textured" and lin_bad.any():
                     bad_total += int(lin_bad.sum())
                     out(f"MISMATCH seed {seed} {kind} {mode}: {int(lin_bad.sum())} pixels whose f64 mean differs in the last bits")
-                if kind == "textured" and bad.sum() <= 2:  # sphere uv goes through atan2 / acos: a last-bit difference may move a sample across a texel edge
+                # sphere uv goes through atan2 / acos: a last-bit difference may move a sample across a texel edge - but only where the oracle saw a lookup within
+                # 4096 ulps of one (po_stats.tex_sphere_near_edge, round 5); a scene without such a lookup must match exactly
+                if kind == "textured" and ref.stats["tex_sphere_near_edge"] > 0 and bad.sum() <= ref.stats["tex_sphere_near_edge"]:
                     tex_edge += int(bad.sum()); bad[:] = False
                 rays_equal = all(st[k] == ref.stats[k] for k in ("primary", "shadow", "reflect", "refract", "hits"))
                 if bad.any() or not rays_equal or st["stack_overflow"]:

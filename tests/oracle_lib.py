@@ -50,7 +50,7 @@ class PoCamera(C.Structure):
 
 class PoStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("primary", "shadow", "reflect", "refract", "depth11", "hits", "n_split",
-                                          "n_leaf", "n_analytic", "n_tri", "n_bbox", "kd_plane_miss")]
+                                          "n_leaf", "n_analytic", "n_tri", "n_bbox", "kd_plane_miss", "tex_sphere_lookups", "tex_sphere_near_edge")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -98,9 +98,10 @@ def test_new_example_matches_oracle(oracle, host, assets, name, mode):
     ps = oracle.pack_arrays(sc.export())
     ref = oracle.render(ps, sc.camera, w, h, samples=2, seed=4, jitter=oracle.JITTER_RNG, mode=omode, threads=8)
     bad = (rgb != ref.rgb).any(axis=2)
-    # sphere texture coordinates go through atan2 / acos (<= 2 ulp apart from glibc): a sample on a texel edge may differ
-    textured_sphere = name == "texture-mapping"
-    assert bad.sum() <= (2 if textured_sphere else 0), f"{bad.sum()} pixels differ, first at {np.argwhere(bad)[:3]}"
+    # sphere texture coordinates go through atan2 / acos (<= 2 ulp apart from glibc): exact all the same, because no lookup of this render comes near a texel
+    # edge - which the oracle counts (tests/test_gpu_textures.py::texel_edge_proof)
+    assert ref.stats["tex_sphere_near_edge"] == 0 and (ref.stats["tex_sphere_lookups"] > 0) == (name == "texture-mapping")
+    assert bad.sum() == 0, f"{bad.sum()} pixels differ, first at {np.argwhere(bad)[:3]}"
     for k in ("primary", "shadow", "reflect", "refract", "hits"):
         assert st[k] == ref.stats[k], k
 

@@ -74,12 +74,11 @@ def test_every_switch_renders_what_the_oracle_renders(oracle, scenes, monkeypatc
             assert st["kernel_variant"] & H.KERNEL_COUNTING and not st0["kernel_variant"] & H.KERNEL_COUNTING, where
             for k in ("primary", "shadow", "reflect", "refract", "hits"):
                 assert st[k] == ref.stats[k], (where, k)
-            textured_sphere = name == "aquarium"  # (its texels hang on atan2 / acos: tests/test_gpu_textures.py)
-            assert int((rgb != ref.rgb).any(axis=2).sum()) <= (2 if textured_sphere else 0), where
+            assert ref.stats["tex_sphere_near_edge"] == 0  # (no sphere texture coordinate near a texel edge: tests/test_gpu_textures.py::texel_edge_proof - so exact)
+            assert np.array_equal(rgb, ref.rgb), where
             assert np.array_equal(plain, rgb), where
-            if not textured_sphere:
-                assert_ulp(linear, ref.linear, 0)
-                assert_ulp(plain_linear, ref.linear, 0)
+            assert_ulp(linear, ref.linear, 0)
+            assert_ulp(plain_linear, ref.linear, 0)
             seen.add((st["kernel_mode"], st["kernel_variant"]))
             seen.add((st0["kernel_mode"], st0["kernel_variant"]))
     assert len(seen) >= 12  # (counting + plain) of several families: the switch did not collapse everything onto one kernel

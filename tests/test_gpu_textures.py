@@ -29,6 +29,16 @@ def host():
     return host
 
 
+def texel_edge_proof(ref):
+    """Sphere texture coordinates go through libm's atan2 / acos (sphere.rs:59-96); the device's routines are within 2 / 1 ulp of glibc's, not bit-equal,
+    and glibc's own are not correctly rounded, so nothing short of glibc's instruction sequence reproduces them (DESIGN 2). A texel can only differ where
+    u (w - 1) or v (h - 1) lies within a few ulps of an integer. The oracle counts the texel fetches whose coordinates came from a sphere hit and those of
+    them within 4096 ulps of a texel edge (po_stats, round 5): none near an edge = the device fetched the same texels, so the comparison below is EXACT -
+    the "<= 2 pixels may differ" of rounds 1 - 4 is gone (VERDICT r04 #8)."""
+    assert ref.stats["tex_sphere_near_edge"] == 0, "a sphere's texture coordinate lies within 4096 ulps of a texel edge: pick another seed / size for this test"
+    return ref.stats["tex_sphere_lookups"]
+
+
 def block_means(a, k=8):
     h, w, _ = a.shape
     h2, w2 = h // k * k, w // k * k
@@ -43,11 +53,9 @@ def test_normal_mapping_example_matches_oracle(oracle, host, H, mode):
     rgb, linear, st = r.render(host_glue.cam10(cam), w, h, default_background(w, h), stats=True)
     ref = oracle.render(scene, cam, w, h, mode=oracle.MODE_KD if mode == "kd" else oracle.MODE_FLAT)
     assert st["hits"] == ref.stats["hits"] and st["shadow"] == ref.stats["shadow"]
-    bad = (rgb != ref.rgb).any(axis=2)
-    # sphere texture coordinates go through atan2 / acos (sphere.rs:57-60): a last-bit difference between
-    # the device and glibc can move a sample across a texel boundary; everything else must be identical
-    assert bad.sum() <= 2, f"{bad.sum()} pixels differ"
-    assert_ulp(linear[~bad], ref.linear[~bad], 0)
+    assert texel_edge_proof(ref) > 0  # (the scene's normal-mapped sphere)
+    assert np.array_equal(rgb, ref.rgb), f"{(rgb != ref.rgb).any(axis=2).sum()} pixels differ"
+    assert_ulp(linear, ref.linear, 0)
 
 
 def test_gpu_normal_mapping_vs_reference_golden(host, H):
@@ -104,9 +112,10 @@ def test_random_textured_scene_matches_oracle(oracle, host, H, seed, mode):
     for k in ("primary", "shadow", "reflect", "hits"):
         assert st[k] == ref.stats[k], k
     assert ref.stats["kd_plane_miss"] == 0
+    texel_edge_proof(ref)
     bad = (rgb != ref.rgb).any(axis=2)
-    assert bad.sum() <= 2, f"{bad.sum()} pixels differ, first at {np.argwhere(bad)[:3]}"
-    assert_ulp(linear[~bad], ref.linear[~bad], 0)
+    assert bad.sum() == 0, f"{bad.sum()} pixels differ, first at {np.argwhere(bad)[:3]}"
+    assert_ulp(linear, ref.linear, 0)
 
 
 def test_texture_on_primitive_without_uv_is_rejected(host, H):
@@ -226,7 +235,8 @@ def test_recursion_frames_all_in_hbm(oracle, host, H, monkeypatch, scene_name, m
     for k in ("primary", "shadow", "reflect", "refract", "hits"):
         assert st[k] == ref.stats[k], k
     bad = (rgb != ref.rgb).any(axis=2)
-    assert bad.sum() <= (2 if scene_name == "textured-1" else 0)  # sphere uv through atan2 / acos: see test_random_textured_scene_matches_oracle
+    texel_edge_proof(ref)
+    assert bad.sum() == 0
     assert np.array_equal(plain, rgb)
 
 

@@ -122,3 +122,19 @@ def test_mesh_equivalence(oracle):  # src/kdtree/kdmesh.rs:99-166
     c_kd = oracle.color_rays(make(KDMesh(model)), o, d, mode=oracle.MODE_HIER)
     assert (c_mesh != 0).any(), "the diagonal must cross the castle"
     assert np.array_equal(c_mesh, c_kd)
+
+
+def test_texel_edge_counters_of_sphere_texture_coordinates(oracle):
+    """po_stats.tex_sphere_lookups / tex_sphere_near_edge (round 5): the GPU tests use them to PROVE that no sphere texture coordinate - the one place where the
+    device's libm (atan2 / acos within 2 / 1 ulp of glibc's) could pick another texel than the reference - comes within 4096 ulps of a texel edge in the renders
+    they compare exactly. Here: the counters count - a textured sphere fetches texels (none of them near an edge in this render), an untextured scene none."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_textures import textured_scene
+    from example_scenes import EXAMPLES
+    sc, cam = textured_scene(1)
+    r = oracle.render(sc, cam, 96, 64, mode=oracle.MODE_FLAT, kd_depth=5)
+    assert r.stats["tex_sphere_lookups"] > 100 and r.stats["tex_sphere_near_edge"] == 0
+    scene, cam2, _ = EXAMPLES["primitives-simple"]()
+    r2 = oracle.render(scene, cam2, 64, 48, mode=oracle.MODE_FLAT)
+    assert r2.stats["tex_sphere_lookups"] == 0 and r2.stats["tex_sphere_near_edge"] == 0
