@@ -1176,6 +1176,7 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // the k-d walk keeps no saved bounds in HBM any more (round 5): its wavefront rows must hold the stack and, where the stack's slack is too small for it, the
     // two rows of the path table (pt_kd_layout, PtKdSav) - also under PORTRAYER_LDS_STACK=1, which then only shrinks the LANES' stacks
     if (kd_sem) a.stack_lds_cap = std::max(a.stack_lds_cap, (a.scene.stack_cap + 63) / 64 + 2);
+    a.grid_share = 1;  // (a share of the resident blocks per launch was tried for ranks that share a GPU, round 5 c23: their kernels do not run side by side - 35.5 -> 14.3 Gray/s)
     uint32_t grid = 0;
     PT_HIP(c, pt_dispatch(a, stats, c->n_cu, stream, &grid, false));
     a.n_lanes = grid * PT_BLOCK;
@@ -1210,8 +1211,8 @@ static int pt_render_common(pt_context* c, PtRenderArgs& a, bool stats, hipStrea
     // + wave_rows: the wavefront's own stack takes LDS rows from the lanes' stacks (pt_wave_rows, pt_render_simple.h): eight, or what a deep tree needs
     const int wave_rows = std::min(std::max(8, (a.scene.stack_cap + 63) / 64), std::max(a.stack_lds_cap, 8));  // (pt_wave_rows: at most this many)
     const int stack_spill_entries = std::max(a.scene.stack_cap - a.stack_lds_cap + wave_rows, 0);
-    a.kd_sav_offset = (uint32_t)std::max(stack_spill_entries, a.scene.stack_cap);  // behind everything a lane's own stack can reach (pt_trace_wave gives the lanes fewer LDS rows in the k-d semantics)
-    if ((rc = pt_reserve(c, sl.stack_spill, (size_t)a.n_lanes * (size_t)a.kd_sav_offset * 4))) return rc;  // (the k-d walk's saved bounds needed columns behind this until round 5)
+    const size_t stack_column = (size_t)std::max(stack_spill_entries, a.scene.stack_cap);  // everything a lane's own stack can reach (pt_trace_wave gives the lanes fewer LDS rows in the k-d semantics)
+    if ((rc = pt_reserve(c, sl.stack_spill, (size_t)a.n_lanes * stack_column * 4))) return rc;  // (the k-d walk's saved bounds needed columns behind this until round 5)
     if ((rc = pt_reserve(c, sl.misc, 256 + sizeof(PtCounters) + PT_FINE_QUEUES * PT_QUEUE_STRIDE * 4))) return rc;
     if ((rc = pt_reserve(c, sl.accum, (size_t)a.n_slots * a.n_chunks * 3 * sizeof(double)))) return rc;
     a.accum = (double*)sl.accum.p;

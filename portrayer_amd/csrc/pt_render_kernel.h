@@ -334,7 +334,8 @@ static hipError_t pt_launch_kernel(size_t lds, const PtRenderArgs& a, int n_cu, 
     }
     uint32_t want = (a.n_items + (PT_BLOCK / 64) - 1) / (PT_BLOCK / 64);
     if (const char* env = getenv("PORTRAYER_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(env)));  // experiment: fewer resident lanes
-    uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), (uint32_t)(n_cu * per_cu));
+    const uint32_t resident = std::max<uint32_t>((uint32_t)(n_cu * per_cu) / std::max<uint32_t>(a.grid_share, 1u), 1u);  // (grid_share: contexts launching side by side on one GPU)
+    uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(want, 1u), resident);
     *grid_out = grid;
     if (!launch) return hipSuccess;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PT_BLOCK), lds, stream, a);

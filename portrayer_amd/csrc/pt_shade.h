@@ -157,7 +157,7 @@ struct PtRenderArgs {
     uint32_t n_lanes;
     uint32_t* stack_spill;           // traversal-stack entries beyond the LDS part, entry x n_lanes
     int32_t stack_lds_cap;           // entries per lane kept in LDS; the rest (up to scene.stack_cap) in stack_spill
-    uint32_t kd_sav_offset;          // k-d semantics, one walk per wavefront: entry of a lane's stack_spill column where its saved range bounds of the top tree levels start (2 words per level)
+    uint32_t grid_share;             // host side only: the launch gets 1 / grid_share of the device's resident blocks (pt_node: ranks that share a GPU; 0 or 1 = all of them)
     int32_t park_slots;              // parked recursion frames per lane kept in LDS (0 or 1; selects the PARK instantiation); older ones in `spill`
     int32_t four_waves;              // the instantiation compiled for more than 3 waves per SIMD (scenes without reflective materials only): 0, or 4 / 5 = the waves
     int32_t run_variant;             // PT_RUN_* (pt_render_kernel.h): which kernel pt_render_common launches

@@ -1870,7 +1870,11 @@ PT_HD void pt_kd_split_eval(double o, double d, double y, pt_mask d_ok, double p
         const double n = plane - o;
         const pt_mask fast = d_ok & pt_div_exp_ok_m(n);
         if (cross & PT_MNOT(fast)) plane_t = n / d;   // some crossing lane's operands are outside the short division's window
+#ifdef PT_KD_RCP_ON_DEMAND
+        else plane_t = pt_div_fast(n, d, pt_rcp_refined(d));
+#else
         else plane_t = pt_div_fast(n, d, y);
+#endif
         strad = cross & pt_in_range_m(start, end, plane_t);
     }
     *s_out = s; *e_out = e; *cross_out = cross; *strad_out = strad; *plane_t_out = plane_t;
@@ -1882,7 +1886,11 @@ PT_HD double pt_kd_plane_t(double o, double d, double y, pt_mask d_ok, double pl
     const double n = plane - o;
     const pt_mask fast = d_ok & pt_div_exp_ok_m(n);
     if (who & PT_MNOT(fast)) return n / d;
+#ifdef PT_KD_RCP_ON_DEMAND
+    return pt_div_fast(n, d, pt_rcp_refined(d));
+#else
     return pt_div_fast(n, d, y);
+#endif
 }
 
 // wstack: the wavefront's own stack (linear, `wwords` words); sav: the lanes' saved bounds per level; lane_stk: the lanes' own stacks
@@ -1903,7 +1911,11 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
     const PtRayPk q = pt_raypk(ray);
     const double extent = sc.kd_extent;
     // per axis: the refined reciprocal of the direction component and whether the short division may be used with it (pt_div_fast)
+#ifdef PT_KD_RCP_ON_DEMAND  // (A/B: the reciprocal refined at every use - five instructions - instead of six registers held for the whole walk; NaN marks "not computed")
+    const double yx = __builtin_nan(""), yy = yx, yz = yx;
+#else
     const double yx = pt_rcp_refined(ray.d.x), yy = pt_rcp_refined(ray.d.y), yz = pt_rcp_refined(ray.d.z);
+#endif
     const pt_mask okx = pt_div_exp_ok_m(ray.d.x), oky = pt_div_exp_ok_m(ray.d.y), okz = pt_div_exp_ok_m(ray.d.z);
     const void* const kd_base = pt_pin_ptr(sc.kd);
     const void* const ref_base = pt_pin_ptr(sc.kd_ref);
