@@ -1919,7 +1919,10 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
     const pt_mask okx = pt_div_exp_ok_m(ray.d.x), oky = pt_div_exp_ok_m(ray.d.y), okz = pt_div_exp_ok_m(ray.d.z);
     const void* const kd_base = pt_pin_ptr(sc.kd);
     const void* const ref_base = pt_pin_ptr(sc.kd_ref);
-    const uint32_t cull = (sc.kd_box != nullptr ? 1u : 0u) | (sc.node_box != nullptr ? 2u : 0u);  // (PORTRAYER_KD_NO_CULL clears both)
+    uint32_t cull = PT_UNIFORM_U32((sc.kd_box != nullptr ? 1u : 0u) | (sc.node_box != nullptr ? 2u : 0u));  // (PORTRAYER_KD_NO_CULL clears both)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_KD_CULL_UNPINNED)
+    asm volatile("" : "+s"(cull));  // (a scalar the walk branches on: left alone the two flags were re-materialised through the vector unit - v_cndmask, v_cmp - at every node and every leaf reference)
+#endif
     uint32_t cur = 0;                 // wave-uniform: node, its level, words on the stack
     int lev = 0, sp = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1983,7 +1986,7 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                 const pt_mask in_first = front_first ? go_f : go_b, in_second = front_first ? go_b : go_f;
                 const bool push = in_second != 0ull;
                 const bool room = sp < wwords;
-                if (room) wstack[sp] = (c_second << 5) | (uint32_t)lev;  // (a free slot when nothing is pushed) one word: the child and the split's level
+                if (room && push) wstack[sp] = (c_second << 5) | (uint32_t)lev;  // one word: the child and the split's level
                 failed = failed || (push && !room);
                 descend = (go_f | go_b) != 0ull && !failed;
                 sp += (push && descend) ? 1 : 0;
@@ -1995,11 +1998,18 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                 if (lev < sav.top_levels) {  // a top level: no slot - the path table gets the split's plane and axis (every lane writes the same words)
                     if (push && descend) { sav.path[3 * lev] = v[0]; sav.path[3 * lev + 1] = v[1]; sav.path[3 * lev + 2] = v[2]; }
                 } else if (both) pt_kd_sav_store(sav, lev, PT_LANES(near_first) ? end : start);
-                uint32_t code = PT_LANES((push && descend) ? in_second : 0ull) ? 1u : 0u;
-                code = PT_LANES(both & near_first) ? 2u : code;
-                code = PT_LANES(both & PT_MNOT(near_first)) ? 3u : code;
-                end = PT_LANES(both & near_first) ? plane_t : end;
-                start = PT_LANES(both & PT_MNOT(near_first)) ? plane_t : start;
+                // (behind wave-uniform branches since round 5: most splits below the top levels push nothing - every lane is on one side - and then there is nothing to select;
+                // the walk is bound by instruction issue, big-scene 27.55 -> 27.27 ms, c28)
+                uint32_t code = 0u;
+                if (push && descend) {
+                    code = PT_LANES(in_second) ? 1u : 0u;
+                    if (both) {
+                        code = PT_LANES(both & near_first) ? 2u : code;
+                        code = PT_LANES(both & PT_MNOT(near_first)) ? 3u : code;
+                        end = PT_LANES(both & near_first) ? plane_t : end;
+                        start = PT_LANES(both & PT_MNOT(near_first)) ? plane_t : start;
+                    }
+                }
                 if (descend) {
                     const int sh = 2 * (lev & 15);
                     if (lev < 16) codes_lo = (codes_lo & ~(3u << sh)) | (code << sh);
