@@ -1227,6 +1227,28 @@ PT_HD void pt_slab_pk2(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned 
     *m1 = PT_FCMP_LE(tn1, tf1);
     *one_first = PT_FCMP_LT(tn1, tn0);
 }
+// The same test handing out the entering parameters as well (pt_descend_mesh's branching form works out which child goes first only where both are reached).
+template <int OCT>
+PT_HD void pt_slab_pk2_t(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned long long* m0, unsigned long long* m1, float* tn0_out, float* tn1_out) {
+    const pt_f32x2 ax = pt_pk_fma_bcast(pt_pair_f32(v[0], v[1]), q.a[0]), ay = pt_pk_fma_bcast(pt_pair_f32(v[2], v[3]), q.a[1]), az = pt_pk_fma_bcast(pt_pair_f32(v[4], v[5]), q.a[2]);
+    const pt_f32x2 bx = pt_pk_fma_bcast(pt_pair_f32(v[6], v[7]), q.b[0]), by = pt_pk_fma_bcast(pt_pair_f32(v[8], v[9]), q.b[1]), bz = pt_pk_fma_bcast(pt_pair_f32(v[10], v[11]), q.b[2]);
+    float tn0, tn1, tf0, tf1;
+    if (OCT == PT_OCT_MIXED) {
+        tn0 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x));
+        tn1 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y));
+        tf0 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.x, bx.x), pt_max2_raw(ay.x, by.x)), pt_max2_raw(az.x, bz.x), tm);
+        tf1 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.y, bx.y), pt_max2_raw(ay.y, by.y)), pt_max2_raw(az.y, bz.y), tm);
+    } else {
+        const pt_f32x2 ex = (OCT & 1) ? bx : ax, lx = (OCT & 1) ? ax : bx;
+        const pt_f32x2 ey = (OCT & 2) ? by : ay, ly = (OCT & 2) ? ay : by;
+        const pt_f32x2 ez = (OCT & 4) ? bz : az, lz = (OCT & 4) ? az : bz;
+        tn0 = pt_max3_zero_raw(pt_max2_raw(ex.x, ey.x), ez.x); tn1 = pt_max3_zero_raw(pt_max2_raw(ex.y, ey.y), ez.y);
+        tf0 = pt_min3_raw(pt_min2_raw(lx.x, ly.x), lz.x, tm); tf1 = pt_min3_raw(pt_min2_raw(lx.y, ly.y), lz.y, tm);
+    }
+    *m0 = PT_FCMP_LE(tn0, tf0);
+    *m1 = PT_FCMP_LE(tn1, tf1);
+    *tn0_out = tn0; *tn1_out = tn1;
+}
 // a lane's exclusive range end as the f32 the slab test compares with, rounded up (inf stays inf)
 PT_HD float pt_tmax32(double t) { float tm = (float)t; return tm + fabsf(tm) * 2.4e-7f; }
 
@@ -1345,6 +1367,49 @@ template <bool STATS, int OCT>
 PT_HD void pt_descend(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned long long lanes, unsigned long long self, uint32_t& cur, int& sp, unsigned long long& in,
                       bool& overflowed, uint32_t* wstack, int words, uint32_t& pops, PtCounters* cnt) {
     constexpr int W = STATS ? 3 : 1;
+#if !defined(PT_STEP_ONE_BLOCK) && defined(__HIP_DEVICE_COMPILE__)  // (-DPT_STEP_ONE_BLOCK: round 3's single block for every case, the A/B of profiles/r05/notes.md section 6)
+    if (!STATS) {  // (see pt_descend_mesh: the common case - one child reached - in six scalar instructions; vote, push and pop behind branches)
+        while (!(cur & PT_REF_LEAF)) {
+            const pt_u32x16 v = pt_sload_node(bvh, cur);
+            PT_WAVE_COUNT(4);
+            unsigned long long m0, m1;
+            float tn0, tn1;
+            pt_slab_pk2_t<OCT>(v, q, tm, &m0, &m1, &tn0, &tn1);
+            uint32_t next, both, f0;
+            asm volatile(
+                "s_and_b64 %[m0], %[m0], %[lanes]\n\t"
+                "s_cselect_b32 %[next], %[c0], %[pop]\n\t"
+                "s_cselect_b32 %[f0], 1, 0\n\t"
+                "s_and_b64 %[m1], %[m1], %[lanes]\n\t"
+                "s_cselect_b32 %[next], %[c1], %[next]\n\t"
+                "s_cselect_b32 %[both], %[f0], 0"
+                : [next] "=&s"(next), [both] "=&s"(both), [f0] "=&s"(f0), [m0] "+s"(m0), [m1] "+s"(m1)
+                : [lanes] "s"(lanes), [c0] "s"(v[12]), [c1] "s"(v[13]), [pop] "s"(PT_REF_POP)
+                : "scc");
+            if (both) {
+                const unsigned long long second_first = m1 & (PT_FCMP_LT(tn1, tn0) | ~m0);
+                const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
+                const uint32_t near = swap ? v[13] : v[12], far = swap ? v[12] : v[13];
+                if (sp + 1 <= words) { wstack[sp] = far; sp++; next = near; }
+                else { overflowed = true; next = PT_REF_EMPTY; }
+            } else if (next == PT_REF_POP) {  // neither: the next pending subtree
+#ifdef PT_WATCH_MESHFREE_DESCEND
+                if (sp > 0 && ++pops <= PT_WALK_POPS_MAX) {
+#else
+                if (sp > 0) {
+#endif
+                    sp--;
+                    next = PT_UNIFORM_U32(wstack[sp]);
+                } else {
+                    overflowed = overflowed || sp > 0;
+                    next = PT_REF_EMPTY;
+                }
+            }
+            cur = next;
+        }
+        return;
+    }
+#endif
     while (!(cur & PT_REF_LEAF)) {
         const pt_u32x16 v = pt_sload_node(bvh, cur);
         PT_WAVE_COUNT(4);
@@ -1391,6 +1456,44 @@ PT_HD void pt_descend(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned
 template <bool STATS, int OCT, bool NEAR = false>
 PT_HD void pt_descend_mesh(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned long long lanes, bool counts, uint32_t& cur, int& sp, uint32_t* wstack, int words,
                            PtCounters* cnt, float t0 = 0.0f) {
+#if !defined(PT_STEP_ONE_BLOCK) && defined(__HIP_DEVICE_COMPILE__)  // (-DPT_STEP_ONE_BLOCK: round 3's single block for every case, the A/B of profiles/r05/notes.md section 6)
+    if (!NEAR) {
+        // Round 5: the step's scalar side by CASES instead of one straight block of mask arithmetic for all of them. About half of the steps reach one child
+        // only (or none); for those the majority vote, the code word and the push logic are never issued - the walk is bound by the scalar unit's issue
+        // rate, not by the fetches (profiles/r05/notes.md section 6: two levels per fetch lost 10 %, eight scalar instructions fewer per step won 5 %).
+        // Same children, same order, same pushes as the single block (the counting build still runs that one).
+        while (!(cur & PT_REF_LEAF)) {
+            const pt_u32x16 v = pt_sload_node(bvh, cur);
+            PT_WAVE_COUNT(4);
+            if (STATS && counts) cnt->n_inner++;
+            unsigned long long m0, m1;
+            float tn0, tn1;
+            pt_slab_pk2_t<OCT>(v, q, tm, &m0, &m1, &tn0, &tn1);
+            // The scalar side of the common case in six instructions: the masks cut down to the participating lanes, `next` = the one child reached (or
+            // PT_REF_POP), `both` = 1 when both are - only then the vote and the push are issued.
+            uint32_t next, both, f0;
+            asm volatile(
+                "s_and_b64 %[m0], %[m0], %[lanes]\n\t"
+                "s_cselect_b32 %[next], %[c0], %[pop]\n\t"
+                "s_cselect_b32 %[f0], 1, 0\n\t"
+                "s_and_b64 %[m1], %[m1], %[lanes]\n\t"
+                "s_cselect_b32 %[next], %[c1], %[next]\n\t"
+                "s_cselect_b32 %[both], %[f0], 0"
+                : [next] "=&s"(next), [both] "=&s"(both), [f0] "=&s"(f0), [m0] "+s"(m0), [m1] "+s"(m1)
+                : [lanes] "s"(lanes), [c0] "s"(v[12]), [c1] "s"(v[13]), [pop] "s"(PT_REF_POP)
+                : "scc");
+            if (both) {  // the one most of the lanes that reach a child enter first (pt_step_decide's vote)
+                const unsigned long long second_first = m1 & (PT_FCMP_LT(tn1, tn0) | ~m0);
+                const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
+                const uint32_t near = swap ? v[13] : v[12], far = swap ? v[12] : v[13];
+                if (sp + 1 <= words) { wstack[sp] = far; sp++; next = near; }
+                else next = PT_REF_EMPTY;
+            }
+            cur = next;
+        }
+        return;
+    }
+#endif
     while (!(cur & PT_REF_LEAF)) {
         const pt_u32x16 v = pt_sload_node(bvh, cur);
         PT_WAVE_COUNT(4);

@@ -1,0 +1,13 @@
+# round 5, call 40: two tree levels per fetch in the wave-uniform mesh walk (fat nodes): parity on mode 1, then A/B
+export PORTRAYER_FAT_NODES=1
+bash profiles/r05/with_objs.sh "1=build/diag/m1_fat.o" timeout 900 python3 -m pytest tests/test_gpu_render_parity.py -q -m gpu -x -k "example_matches or device_built or synthetic or mesh or random_scene" > gpurun_out/c40_tests.txt 2>&1; tail -2 gpurun_out/c40_tests.txt
+line() { python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().split('\n')[-1])
+print('%-72s %9.1f Mray/s %8.3f ms/frame' % ('$1', d['value'], d['ms_per_step']))"; }
+for rep in 1 2; do
+for a in "--workload big-soup --samples 64" "--workload big-mesh --samples 64" "--workload cows" "--workload mirror"; do
+  python3 bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2 $a 2>/dev/null | line "shipped $a"
+  bash profiles/r05/with_objs.sh "1=build/diag/m1_fat.o" python3 bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2 $a 2>/dev/null | line "fat nodes $a"
+done; done > gpurun_out/c40_fat.txt 2>&1
+cat gpurun_out/c40_fat.txt
