@@ -1228,21 +1228,27 @@ PT_HD void pt_slab_pk2(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned 
     *one_first = PT_FCMP_LT(tn1, tn0);
 }
 // The same test handing out the entering parameters as well (pt_descend_mesh's branching form works out which child goes first only where both are reached).
-template <int OCT>
-PT_HD void pt_slab_pk2_t(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned long long* m0, unsigned long long* m1, float* tn0_out, float* tn1_out) {
+template <int OCT, bool NEAR = false>
+PT_HD void pt_slab_pk2_t(const pt_u32x16& v, const PtRayPk& q, float tm, unsigned long long* m0, unsigned long long* m1, float* tn0_out, float* tn1_out, float t0 = 0.0f) {
     const pt_f32x2 ax = pt_pk_fma_bcast(pt_pair_f32(v[0], v[1]), q.a[0]), ay = pt_pk_fma_bcast(pt_pair_f32(v[2], v[3]), q.a[1]), az = pt_pk_fma_bcast(pt_pair_f32(v[4], v[5]), q.a[2]);
     const pt_f32x2 bx = pt_pk_fma_bcast(pt_pair_f32(v[6], v[7]), q.b[0]), by = pt_pk_fma_bcast(pt_pair_f32(v[8], v[9]), q.b[1]), bz = pt_pk_fma_bcast(pt_pair_f32(v[10], v[11]), q.b[2]);
     float tn0, tn1, tf0, tf1;
     if (OCT == PT_OCT_MIXED) {
-        tn0 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x));
-        tn1 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y));
+        if (NEAR) {
+            tn0 = pt_max3_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x), t0);
+            tn1 = pt_max3_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y), t0);
+        } else {
+            tn0 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.x, bx.x), pt_min2_raw(ay.x, by.x)), pt_min2_raw(az.x, bz.x));
+            tn1 = pt_max3_zero_raw(pt_max2_raw(pt_min2_raw(ax.y, bx.y), pt_min2_raw(ay.y, by.y)), pt_min2_raw(az.y, bz.y));
+        }
         tf0 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.x, bx.x), pt_max2_raw(ay.x, by.x)), pt_max2_raw(az.x, bz.x), tm);
         tf1 = pt_min3_raw(pt_min2_raw(pt_max2_raw(ax.y, bx.y), pt_max2_raw(ay.y, by.y)), pt_max2_raw(az.y, bz.y), tm);
     } else {
         const pt_f32x2 ex = (OCT & 1) ? bx : ax, lx = (OCT & 1) ? ax : bx;
         const pt_f32x2 ey = (OCT & 2) ? by : ay, ly = (OCT & 2) ? ay : by;
         const pt_f32x2 ez = (OCT & 4) ? bz : az, lz = (OCT & 4) ? az : bz;
-        tn0 = pt_max3_zero_raw(pt_max2_raw(ex.x, ey.x), ez.x); tn1 = pt_max3_zero_raw(pt_max2_raw(ex.y, ey.y), ez.y);
+        if (NEAR) { tn0 = pt_max3_raw(pt_max2_raw(ex.x, ey.x), ez.x, t0); tn1 = pt_max3_raw(pt_max2_raw(ex.y, ey.y), ez.y, t0); }
+        else { tn0 = pt_max3_zero_raw(pt_max2_raw(ex.x, ey.x), ez.x); tn1 = pt_max3_zero_raw(pt_max2_raw(ex.y, ey.y), ez.y); }
         tf0 = pt_min3_raw(pt_min2_raw(lx.x, ly.x), lz.x, tm); tf1 = pt_min3_raw(pt_min2_raw(lx.y, ly.y), lz.y, tm);
     }
     *m0 = PT_FCMP_LE(tn0, tf0);
@@ -1457,7 +1463,7 @@ template <bool STATS, int OCT, bool NEAR = false>
 PT_HD void pt_descend_mesh(const PtBvhNode* bvh, const PtRayPk& q, float tm, unsigned long long lanes, bool counts, uint32_t& cur, int& sp, uint32_t* wstack, int words,
                            PtCounters* cnt, float t0 = 0.0f) {
 #if !defined(PT_STEP_ONE_BLOCK) && defined(__HIP_DEVICE_COMPILE__)  // (-DPT_STEP_ONE_BLOCK: round 3's single block for every case, the A/B of profiles/r05/notes.md section 6)
-    if (!NEAR) {
+    {
         // Round 5: the step's scalar side by CASES instead of one straight block of mask arithmetic for all of them. About half of the steps reach one child
         // only (or none); for those the majority vote, the code word and the push logic are never issued - the walk is bound by the scalar unit's issue
         // rate, not by the fetches (profiles/r05/notes.md section 6: two levels per fetch lost 10 %, eight scalar instructions fewer per step won 5 %).
@@ -1468,7 +1474,7 @@ PT_HD void pt_descend_mesh(const PtBvhNode* bvh, const PtRayPk& q, float tm, uns
             if (STATS && counts) cnt->n_inner++;
             unsigned long long m0, m1;
             float tn0, tn1;
-            pt_slab_pk2_t<OCT>(v, q, tm, &m0, &m1, &tn0, &tn1);
+            pt_slab_pk2_t<OCT, NEAR>(v, q, tm, &m0, &m1, &tn0, &tn1, t0);
             // The scalar side of the common case in six instructions: the masks cut down to the participating lanes, `next` = the one child reached (or
             // PT_REF_POP), `both` = 1 when both are - only then the vote and the push are issued.
             uint32_t next, both, f0;
