@@ -1603,6 +1603,52 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     }
 }
 
+// The walk of ONE mesh instance's triangle tree (round 5), compiled once per octant of the participating lanes' rays: descents, triangle leaves and the
+// pops between them stay inside the specialised code until the instance's part of the stack is used up (`sp` back at its value on entry - no marker entry, no
+// marker test per pop, no re-dispatch on the octant per descent). Returns 0: instance finished, 1: stack overflow / watchdog, 2: no lane wants candidates any more.
+template <bool STATS, bool HIER, int OCT>
+PT_HD int pt_walk_instance(const PtSceneView& sc, uint32_t inst, uint32_t root, const PtRay& local, const PtRayPk& q, bool part, bool any, bool& alive, PtHit& best, float& tm,
+                           uint32_t* wstack, int& sp, int words, uint32_t& pops, PtCounters* cnt) {
+    const int sp0 = sp;
+    uint32_t cur = root;
+    unsigned long long pmask = PT_BALLOT(alive && part);
+    for (;;) {
+        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt);
+        if (cur == PT_REF_EMPTY) return 1;
+        if (cur != PT_REF_POP) {
+            const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+            PT_WAVE_COUNT(5);
+            if (STATS && alive && part) cnt->n_leaf++;
+            PT_CYC_BEGIN();
+            for (uint32_t i = 0; i < count; i++) {
+                pt_u32x16 a;
+                uint32_t b0, b1;
+                const uint32_t tri = pt_load_leaf_triangle(sc, first + i, a, b0, b1);
+                double tv[9];
+#pragma unroll
+                for (int k = 0; k < 8; k++) tv[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
+                tv[8] = pt_f64_of(b0, b1);
+                if (alive && part) {
+                    double tt, beta, gamma;
+                    if (STATS) cnt->n_tri++;
+                    if (PT_TRI_HIT(tv, local, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, inst, tri), &tt, &beta, &gamma)) {
+                        best.t = tt; best.node = inst; best.sub = tri;
+                        tm = pt_tmax32(tt);
+                        if (any) alive = false;
+                    }
+                }
+            }
+            PT_CYC_END(5);
+            if (!PT_BALLOT(alive)) return 2;
+            pmask = PT_BALLOT(alive && part);
+        }
+        if (sp == sp0) return 0;
+        if (++pops > PT_WALK_POPS_MAX) return 1;
+        sp--;
+        cur = PT_UNIFORM_U32(wstack[sp]);
+    }
+}
+
 // The same for scenes WITH mesh instances (PT_MODE_FLAT, hits spawn no rays): the scene tree and every mesh's triangle tree are
 // walked once per wavefront. Entering a mesh instance is wave-uniform too: every lane brings its ray into the instance's space
 // with the one inverse transform (scalar operands), the lanes whose rays pass the mesh's exact box test (mesh.rs:146-155) take
@@ -1725,6 +1771,26 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         const bool inside = alive && pt_bbox_test_hit(bi, lr, PT_EPSILON, pt_cand_end_in<HIER>(sc, best, node, 0));
                         const unsigned long long inside_mask = PT_BALLOT(inside);
                         if (!inside_mask) continue;
+#ifndef PT_MESH_MARKER_WALK
+                        {   // the instance's tree, in the code of its octant (pt_walk_instance); the scene-level walk goes on with this leaf's next node afterwards
+                            int io = PT_OCT_MIXED;
+                            const PtRayPk qi = (sc.mesh_oct && !STATS) ? pt_raypk(lr, inside, &io) : pt_raypk(lr);
+                            int rc;
+                            switch (io) {
+                            case 0: rc = pt_walk_instance<STATS, HIER, 0>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            case 1: rc = pt_walk_instance<STATS, HIER, 1>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            case 2: rc = pt_walk_instance<STATS, HIER, 2>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            case 3: rc = pt_walk_instance<STATS, HIER, 3>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            case 4: rc = pt_walk_instance<STATS, HIER, 4>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            case 5: rc = pt_walk_instance<STATS, HIER, 5>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            case 6: rc = pt_walk_instance<STATS, HIER, 6>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            case 7: rc = pt_walk_instance<STATS, HIER, 7>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            default: rc = pt_walk_instance<STATS, HIER, PT_OCT_MIXED>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
+                            }
+                            if (rc == 1) { overflowed(); return; }
+                            if (rc == 2) return;
+                        }
+#else
                         if (sp + 2 > words) { overflowed(); return; }
                         if (i + 1 < count) { slot(sp) = PT_REF_LEAF | ((first + i + 1) << 3) | (count - i - 2); sp++; }  // the rest of this leaf
                         slot(sp) = PT_REF_MARKER; sp++;
@@ -1733,6 +1799,7 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                         else q = pt_raypk(lr);
                         cur = root;
                         entered = true;
+#endif
                     } else if (alive) {
                         if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, identity_ok, best, cnt)) {
                             tm = pt_tmax32(best.t);
