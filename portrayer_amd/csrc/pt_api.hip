@@ -856,7 +856,9 @@ extern "C" int pt_scene_upload(pt_context* c, const pt_scene* s, int traverse, c
         c->five_waves = c->four_waves && s->n_meshes == 0 && traverse != PT_TRAVERSE_KD;
         // ... and so do scenes of very many triangles in plain Mesh instances (round 4, c29: their walks wait for node fetches - 3 -> 4 waves was +18 % -; the 1.25 M-triangle
         // scenes +3.7 % / +3.2 %, hierarchical +2.6 %, at 96 registers with 57 spilled; macho-cows, 17,500 triangles, loses 15 % and stays at 4)
-        c->five_waves_mesh = !c->spawns && plain_meshes && instanced_tris >= 65536 && (traverse == PT_TRAVERSE_FLAT || traverse == PT_TRAVERSE_HIER);
+        // Round 5 (c47 / c48, after the tree step and the instance walk issue fewer scalar instructions): flat_scene is now FASTER at 4 waves (big-soup 18.96 -> 18.75 ms,
+        // big-mesh 19.16 -> 18.86; 18 spilled registers instead of 69) and takes 4; the hierarchical semantics still gain 1 % at 5 and keep them.
+        c->five_waves_mesh = !c->spawns && plain_meshes && instanced_tris >= 65536 && traverse == PT_TRAVERSE_HIER;
     }
     std::vector<double> lights(s->lights, s->lights + 15 * (size_t)s->n_lights);
     {   // fork / join of refracted subtrees (pt_shade.h) needs a recursion that draws no random numbers and a dielectric material to be of use

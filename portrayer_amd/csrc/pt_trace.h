@@ -1981,10 +1981,9 @@ PT_HD double pt_kd_sav_load(const PtKdSav& s, int level) {
 // like pt_trace_packet_mesh does, every triangle tested over [start, end of the lane's leaf fold) - nearest triangle, lowest index on
 // exact ties (pt_cand_end), which is what the reference's fold over ALL triangles with a shrinking range gives. `wstack`: free words
 // of the wavefront's stack. Returns false when they ran out.
-template <bool STATS>
-PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_t root, const PtRay& local, bool part, double start, bool any, PtHit& lb, bool& found,
-                                   uint32_t* wstack, int words, PtCounters* cnt) {
-    const PtRayPk q = pt_raypk(local);
+template <bool STATS, int OCT>
+PT_HD bool pt_packet_mesh_below_kd_oct(const PtSceneView& sc, uint32_t inst, uint32_t root, const PtRay& local, const PtRayPk& q, bool part, double start, bool any, PtHit& lb, bool& found,
+                                       uint32_t* wstack, int words, PtCounters* cnt) {
     float tm = pt_tmax32(lb.t);
     // the lane's range starts at `start` (the k-d leaf's): boxes that end before it hold no hit of this leaf - a mesh that spans several k-d leaves
     // is walked once per leaf, each time only where the leaf's range reaches (round 4). Rounded down like the k-d walk's own segment culls.
@@ -1999,7 +1998,7 @@ PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_
     int sp = 0;
     uint32_t steps = 0;  // (watchdog, as in pt_trace_packet_kd: leaves visited)
     for (;;) {
-        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, PT_OCT_MIXED, true>(sc.bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt, t0);
+        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT, true>(sc.bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt, t0);
         steps++;
         if (cur == PT_REF_EMPTY || steps > PT_KD_WALK_STEPS_MAX) return false;
         if (cur != PT_REF_POP) {
@@ -2030,6 +2029,27 @@ PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_
         if (sp == 0) return true;
         sp--;
         cur = PT_UNIFORM_U32(wstack[sp]);
+    }
+}
+
+// (round 5: in the code of the octant the participating lanes' rays share inside the instance, like pt_walk_instance - worked out once per call)
+template <bool STATS>
+PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_t root, uint32_t tri_count, const PtRay& local, bool part, double start, bool any, PtHit& lb, bool& found,
+                                   uint32_t* wstack, int words, PtCounters* cnt) {
+    // (only for trees deep enough to earn the octant's bookkeeping back: the 1.25 M-triangle soup +5.4 %; the mirror scene's and macho-cows' few-thousand-triangle
+    // meshes, walked once per k-d leaf they span, lose 6.6 % / 3.7 % with it - c49)
+    int oct = PT_OCT_MIXED;
+    const PtRayPk q = (sc.mesh_oct && !STATS && tri_count >= 65536u) ? pt_raypk(local, part, &oct) : pt_raypk(local);
+    switch (oct) {
+    case 0: return pt_packet_mesh_below_kd_oct<STATS, 0>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 1: return pt_packet_mesh_below_kd_oct<STATS, 1>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 2: return pt_packet_mesh_below_kd_oct<STATS, 2>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 3: return pt_packet_mesh_below_kd_oct<STATS, 3>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 4: return pt_packet_mesh_below_kd_oct<STATS, 4>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 5: return pt_packet_mesh_below_kd_oct<STATS, 5>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 6: return pt_packet_mesh_below_kd_oct<STATS, 6>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 7: return pt_packet_mesh_below_kd_oct<STATS, 7>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    default: return pt_packet_mesh_below_kd_oct<STATS, PT_OCT_MIXED>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
     }
 }
 
@@ -2253,7 +2273,7 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                             if (root == PT_REF_EMPTY) continue;
                             const bool inside = test_l && pt_bbox_test_hit(bi, local, start, pt_cand_end(lb, item, 0));
                             if (!pt_any(inside)) continue;
-                            if (!pt_packet_mesh_below_kd<STATS>(sc, item, root, local, inside, start, PT_LANES(any_m), lb, hit, wstack + sp, wwords - sp, cnt)) failed = true;
+                            if (!pt_packet_mesh_below_kd<STATS>(sc, item, root, head[1], local, inside, start, PT_LANES(any_m), lb, hit, wstack + sp, wwords - sp, cnt)) failed = true;
                         }
                     } else if (test_l) {
                         double t; uint32_t part = 0;

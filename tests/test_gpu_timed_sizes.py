@@ -54,8 +54,8 @@ def test_synthetic_million_triangle_scenes_at_the_timed_size(oracle, host, H, na
     rgb, _, timed = r.render(sc.camera, w, h, bg, samples=samples, seed=0, sample_mode=H.SAMPLE_RNG, want_linear=False)
     r.close()
     assert np.array_equal(counted, rgb), "the counting and the timed instantiation must render the same image"
-    assert timed["kernel_mode"] == mode_id and timed["kernel_variant"] == 5, "the default for these scenes: straight-line kernel, 5 waves per SIMD (round 4), untextured"
-    assert st["kernel_variant"] == (5 | H.KERNEL_COUNTING)
+    assert timed["kernel_mode"] == mode_id and timed["kernel_variant"] == 4, "the default for these scenes in flat_scene: straight-line kernel, 4 waves per SIMD (round 5, c47; the hierarchical semantics take 5), untextured"
+    assert st["kernel_variant"] == (4 | H.KERNEL_COUNTING)
     assert st["primary"] == w * h * samples and st["shadow"] == 3 * st["hits"] and st["reflect"] == 0 and st["stack_overflow"] == 0
     ps = oracle.pack_arrays(sc.export())
     check_pixels_in_parallel(oracle, ps, sc.camera, rgb, w, h, samples, oracle.MODE_FLAT, pick_pixels(rgb, 16, 16))
