@@ -1603,6 +1603,17 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     }
 }
 
+// A wave-uniform pointer pinned to a scalar register pair (see pt_args_again: what is read through the re-read argument block would
+// otherwise be fetched again - one more dependent scalar load - in front of every use inside a loop).
+PT_HD const void* pt_pin_ptr(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long a = (unsigned long long)pt_uniform_ptr(p);
+    asm volatile("" : "+s"(a));
+    return (const void*)a;
+#else
+    return p;
+#endif
+}
 // The walk of ONE mesh instance's triangle tree (round 5), compiled once per octant of the participating lanes' rays: descents, triangle leaves and the
 // pops between them stay inside the specialised code until the instance's part of the stack is used up (`sp` back at its value on entry - no marker entry, no
 // marker test per pop, no re-dispatch on the octant per descent). Returns 0: instance finished, 1: stack overflow / watchdog, 2: no lane wants candidates any more.
@@ -1612,8 +1623,11 @@ PT_HD int pt_walk_instance(const PtSceneView& sc, uint32_t inst, uint32_t root, 
     const int sp0 = sp;
     uint32_t cur = root;
     unsigned long long pmask = PT_BALLOT(alive && part);
+    // (the tree's base address pinned to a scalar register pair: read through the re-read argument block it is a value the compiler may fetch again wherever it is
+    // short of registers - and it did, in front of every node fetch of every step: one more dependent round trip through the scalar cache per step)
+    const PtBvhNode* const bvh = static_cast<const PtBvhNode*>(pt_pin_ptr(sc.bvh));
     for (;;) {
-        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt);
+        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt);
         if (cur == PT_REF_EMPTY) return 1;
         if (cur != PT_REF_POP) {
             const uint32_t first = (cur & ~PT_REF_LEAF) >> 3, count = (cur & 7u) + 1u;
@@ -1913,17 +1927,6 @@ PT_HD bool pt_any(bool b) {
     return b;
 #endif
 }
-// A wave-uniform pointer pinned to a scalar register pair (see pt_args_again: what is read through the re-read argument block would
-// otherwise be fetched again - one more dependent scalar load - in front of every use inside a loop).
-PT_HD const void* pt_pin_ptr(const void* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long a = (unsigned long long)pt_uniform_ptr(p);
-    asm volatile("" : "+s"(a));
-    return (const void*)a;
-#else
-    return p;
-#endif
-}
 // 8 dwords at base + byte offset (32 bits): one scalar load, no 64-bit address arithmetic
 PT_HD pt_u32x8 pt_sload8_off(const void* base, uint32_t byte_off) {
     pt_u32x8 v;
@@ -1997,8 +2000,9 @@ PT_HD bool pt_packet_mesh_below_kd_oct(const PtSceneView& sc, uint32_t inst, uin
     uint32_t cur = root;
     int sp = 0;
     uint32_t steps = 0;  // (watchdog, as in pt_trace_packet_kd: leaves visited)
+    const PtBvhNode* const bvh = static_cast<const PtBvhNode*>(pt_pin_ptr(sc.bvh));  // (see pt_walk_instance)
     for (;;) {
-        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT, true>(sc.bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt, t0);
+        if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT, true>(bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt, t0);
         steps++;
         if (cur == PT_REF_EMPTY || steps > PT_KD_WALK_STEPS_MAX) return false;
         if (cur != PT_REF_POP) {
