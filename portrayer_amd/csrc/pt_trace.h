@@ -1091,6 +1091,20 @@ PT_HD uint32_t pt_load_leaf_triangle(const PtSceneView& sc, uint32_t slot, pt_u3
 #define PT_TRI_REC(sc) (sc).tri_e
 #define PT_TRI_HIT pt_triangle_hit_e
 #endif
+// (the same from a base address the caller holds in scalar registers - pt_pin_ptr(sc.tri_leaf) -: read through the scene view it was fetched again for every triangle)
+PT_HD uint32_t pt_load_leaf_triangle_at(const double* tri_leaf, uint32_t slot, pt_u32x16& a, uint32_t& b0, uint32_t& b1) {
+    const double* rec = tri_leaf + 10 * (size_t)slot;
+#if defined(__HIP_DEVICE_COMPILE__)
+    pt_u32x4 b;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(rec)) : "memory");
+    b0 = b[0]; b1 = b[1];
+    return b[2];
+#else
+    a = *reinterpret_cast<const pt_u32x16*>(rec);
+    b0 = reinterpret_cast<const uint32_t*>(rec)[16]; b1 = reinterpret_cast<const uint32_t*>(rec)[17];
+    return reinterpret_cast<const uint32_t*>(rec)[18];
+#endif
+}
 PT_HD uint32_t pt_load_leaf_triangle(const PtSceneView& sc, uint32_t slot, pt_u32x16& a, uint32_t& b0, uint32_t& b1) {
 #if defined(PT_TRI_VIA_ITEMS) || defined(PT_NO_TRI_EDGES)
     const uint32_t tri = PT_UNIFORM_U32(sc.bvh_items[slot]);
@@ -1626,6 +1640,9 @@ PT_HD int pt_walk_instance(const PtSceneView& sc, uint32_t inst, uint32_t root, 
     // (the tree's base address pinned to a scalar register pair: read through the re-read argument block it is a value the compiler may fetch again wherever it is
     // short of registers - and it did, in front of every node fetch of every step: one more dependent round trip through the scalar cache per step)
     const PtBvhNode* const bvh = static_cast<const PtBvhNode*>(pt_pin_ptr(sc.bvh));
+#if !defined(PT_TRI_VIA_ITEMS) && !defined(PT_NO_TRI_EDGES)
+    const double* const tri_leaf = static_cast<const double*>(pt_pin_ptr(sc.tri_leaf));
+#endif
     for (;;) {
         if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt);
         if (cur == PT_REF_EMPTY) return 1;
@@ -1637,7 +1654,11 @@ PT_HD int pt_walk_instance(const PtSceneView& sc, uint32_t inst, uint32_t root, 
             for (uint32_t i = 0; i < count; i++) {
                 pt_u32x16 a;
                 uint32_t b0, b1;
+                #if !defined(PT_TRI_VIA_ITEMS) && !defined(PT_NO_TRI_EDGES)
+                const uint32_t tri = pt_load_leaf_triangle_at(tri_leaf, first + i, a, b0, b1);
+#else
                 const uint32_t tri = pt_load_leaf_triangle(sc, first + i, a, b0, b1);
+#endif
                 double tv[9];
 #pragma unroll
                 for (int k = 0; k < 8; k++) tv[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
@@ -1690,6 +1711,15 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     auto slot = [&](int k) -> uint32_t& { return wstack[k]; };
     const int words = wwords < sc.stack_cap ? wwords : sc.stack_cap;
     uint32_t pops = 0;  // (watchdog: pending subtrees taken by this walk; one that takes more than any tree has nodes ends like a stack overflow)
+#if defined(PT_PIN_SCENE_PTRS)  // (A/B: the arrays a mesh instance is entered through, held in scalar registers for the whole walk instead of re-read from the argument block at every scene-level leaf)
+    const uint32_t* const info_base = static_cast<const uint32_t*>(pt_pin_ptr(sc.info));
+    const double* const inv_base = static_cast<const double*>(pt_pin_ptr(sc.inv));
+    const PtMeshInfo* const meshes_base = static_cast<const PtMeshInfo*>(pt_pin_ptr(sc.meshes));
+#else
+    const uint32_t* const info_base = sc.info;
+    const double* const inv_base = sc.inv;
+    const PtMeshInfo* const meshes_base = sc.meshes;
+#endif
     auto overflowed = [&]() {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (overflow) atomicOr(overflow, pops > PT_WALK_POPS_MAX ? 4u : 1u);  // 4: the watchdog
@@ -1750,17 +1780,17 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
                     const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
                     // (fetches that depend on each other cost a round trip through the scalar cache each - a mesh instance is entered with three: the
                     // node's {type, data, ..}, its inverse, the mesh record's {box inverse, roots} - not with one per field: round 4, c47)
-                    const pt_u32x4 info4 = pt_sload4(sc.info + 4 * (size_t)node);
+                    const pt_u32x4 info4 = pt_sload4(info_base + 4 * (size_t)node);
                     const uint32_t type = info4[0];
                     if (type == PT_MESH || type == PT_KDMESH) {
                         const uint32_t data = info4[1];
-                        const PtMeshInfo* mi = sc.meshes + data;
+                        const PtMeshInfo* mi = meshes_base + data;
                         PtRay lr;
                         if (HIER) {
                             lr = pt_node_local_ray_uniform(sc, node, ray, identity_ok);
                         } else {
                             double m[12];
-                            pt_sload_mat12(sc.inv + 12 * (size_t)node, m);
+                            pt_sload_mat12(inv_base + 12 * (size_t)node, m);
                             lr = pt_ray_to_local(m, ray);
                         }
                         if (STATS && alive) cnt->n_analytic++;
@@ -2001,6 +2031,9 @@ PT_HD bool pt_packet_mesh_below_kd_oct(const PtSceneView& sc, uint32_t inst, uin
     int sp = 0;
     uint32_t steps = 0;  // (watchdog, as in pt_trace_packet_kd: leaves visited)
     const PtBvhNode* const bvh = static_cast<const PtBvhNode*>(pt_pin_ptr(sc.bvh));  // (see pt_walk_instance)
+#if !defined(PT_TRI_VIA_ITEMS) && !defined(PT_NO_TRI_EDGES)
+    const double* const tri_leaf = static_cast<const double*>(pt_pin_ptr(sc.tri_leaf));
+#endif
     for (;;) {
         if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT, true>(bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt, t0);
         steps++;
@@ -2011,7 +2044,11 @@ PT_HD bool pt_packet_mesh_below_kd_oct(const PtSceneView& sc, uint32_t inst, uin
             for (uint32_t i = 0; i < count; i++) {
                 pt_u32x16 a;
                 uint32_t b0, b1;
+                #if !defined(PT_TRI_VIA_ITEMS) && !defined(PT_NO_TRI_EDGES)
+                const uint32_t tri = pt_load_leaf_triangle_at(tri_leaf, first + i, a, b0, b1);
+#else
                 const uint32_t tri = pt_load_leaf_triangle(sc, first + i, a, b0, b1);
+#endif
                 double tv[9];
 #pragma unroll
                 for (int k = 0; k < 8; k++) tv[k] = pt_f64_of(a[2 * k], a[2 * k + 1]);
