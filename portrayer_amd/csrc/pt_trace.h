@@ -1506,8 +1506,12 @@ PT_HD void pt_descend_mesh(const PtBvhNode* bvh, const PtRayPk& q, float tm, uns
                 const unsigned long long second_first = m1 & (PT_FCMP_LT(tn1, tn0) | ~m0);
                 const bool swap = __builtin_popcountll(second_first) * 2 > __builtin_popcountll(m0 | m1);
                 const uint32_t near = swap ? v[13] : v[12], far = swap ? v[12] : v[13];
+#ifdef PT_NO_PUSH_CHECK  // (A/B only: what the overflow test of a push costs)
+                wstack[sp] = far; sp++; next = near;
+#else
                 if (sp + 1 <= words) { wstack[sp] = far; sp++; next = near; }
                 else next = PT_REF_EMPTY;
+#endif
             }
             cur = next;
         }
@@ -1678,7 +1682,9 @@ PT_HD int pt_walk_instance(const PtSceneView& sc, uint32_t inst, uint32_t root, 
             pmask = PT_BALLOT(alive && part);
         }
         if (sp == sp0) return 0;
+#ifndef PT_NO_INSTANCE_WATCHDOG  // (A/B only: what the watchdog costs)
         if (++pops > PT_WALK_POPS_MAX) return 1;
+#endif
         sp--;
         cur = PT_UNIFORM_U32(wstack[sp]);
     }
@@ -1711,6 +1717,9 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
     auto slot = [&](int k) -> uint32_t& { return wstack[k]; };
     const int words = wwords < sc.stack_cap ? wwords : sc.stack_cap;
     uint32_t pops = 0;  // (watchdog: pending subtrees taken by this walk; one that takes more than any tree has nodes ends like a stack overflow)
+    // (the scene-level steps' base address: pinned in the instantiations with KDMesh trees, whose walks are mostly scene-level steps - the dielectric workload +1.0 %, its hierarchical form +1.6 %; left to
+    // the compiler in the others, where the pair of registers costs the mirror scene 0.4 % - c55)
+    const PtBvhNode* const bvh = KDMESH ? static_cast<const PtBvhNode*>(pt_pin_ptr(sc.bvh)) : sc.bvh;
 #if defined(PT_PIN_SCENE_PTRS)  // (A/B: the arrays a mesh instance is entered through, held in scalar registers for the whole walk instead of re-read from the argument block at every scene-level leaf)
     const uint32_t* const info_base = static_cast<const uint32_t*>(pt_pin_ptr(sc.info));
     const double* const inv_base = static_cast<const double*>(pt_pin_ptr(sc.inv));
@@ -1736,15 +1745,15 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
         // instance entered; the scene-level steps keep the per-lane form): 37 steps per ray on the 1.25 M-triangle soup +6 %, the short walks no longer lose.
         if (!(cur & PT_REF_LEAF)) {
             switch (STATS ? PT_OCT_MIXED : oct) {
-            case 0: pt_descend_mesh<STATS, 0>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
-            case 1: pt_descend_mesh<STATS, 1>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
-            case 2: pt_descend_mesh<STATS, 2>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
-            case 3: pt_descend_mesh<STATS, 3>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
-            case 4: pt_descend_mesh<STATS, 4>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
-            case 5: pt_descend_mesh<STATS, 5>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
-            case 6: pt_descend_mesh<STATS, 6>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
-            case 7: pt_descend_mesh<STATS, 7>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
-            default: pt_descend_mesh<STATS, PT_OCT_MIXED>(sc.bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 0: pt_descend_mesh<STATS, 0>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 1: pt_descend_mesh<STATS, 1>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 2: pt_descend_mesh<STATS, 2>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 3: pt_descend_mesh<STATS, 3>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 4: pt_descend_mesh<STATS, 4>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 5: pt_descend_mesh<STATS, 5>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 6: pt_descend_mesh<STATS, 6>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            case 7: pt_descend_mesh<STATS, 7>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
+            default: pt_descend_mesh<STATS, PT_OCT_MIXED>(bvh, q, tm, pmask, alive && part, cur, sp, wstack, words, cnt); break;
             }
         }
         if (cur == PT_REF_EMPTY) { overflowed(); return; }
