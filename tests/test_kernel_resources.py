@@ -66,7 +66,7 @@ CEILINGS = {
     ("line", 7, False, False, 4, False): 12,    # (10)
     ("line", 1, False, False, 5, False): 75,    # big-soup / big-mesh (69; 57 before the instance walk became a call per octant - which is 1 - 6 % faster: c46)
     ("line", 1, False, False, 4, False): 24,    # macho-cows (18; 7 before, see above: +4 %)
-    ("line", 1, False, False, 4, True): 48,     # the mirror scene's chain kernel (43; 38 before, see above: +6 %)
+    ("line", 1, False, False, 4, True): 54,     # the mirror scene's chain kernel (49 with the pinned base addresses; 38 before the instance walk became a call: +6 %)
     ("interp", 4, False, True, 1, False): 104,  # transmission-refraction: textured interpreter, maps applied before the state machine (94; 108 with 8 of them in the loop before)
     ("interp", 4, False, False, 1, False): 20,  # ... untextured (16)
     ("interp", 5, False, True, 1, False): 16,   # the same scene in the hierarchical semantics (12)
