@@ -1323,26 +1323,19 @@ PT_HD pt_u32x16 pt_sload_node(const void* base, uint32_t index) {
 
 // One flattened node against every participating lane's ray; `node` is wave-uniform.
 template <bool STATS, bool HIER>
-PT_HD bool pt_test_node_uniform_at(const PtSceneView& sc, const uint32_t* info_base, const double* inv_base, uint32_t node, const PtRay& ray, bool identity_ok, PtHit& best, PtCounters* cnt);
-template <bool STATS, bool HIER>
 PT_HD bool pt_test_node_uniform(const PtSceneView& sc, uint32_t node, const PtRay& ray, bool identity_ok, PtHit& best, PtCounters* cnt) {
-    return pt_test_node_uniform_at<STATS, HIER>(sc, sc.info, HIER ? sc.own_inv : sc.inv, node, ray, identity_ok, best, cnt);
-}
-// (info_base / inv_base: sc.info and sc.inv - HIER: sc.own_inv -, or the same addresses held in scalar registers by the caller: pt_pin_ptr)
-template <bool STATS, bool HIER>
-PT_HD bool pt_test_node_uniform_at(const PtSceneView& sc, const uint32_t* info_base, const double* inv_base, uint32_t node, const PtRay& ray, bool identity_ok, PtHit& best, PtCounters* cnt) {
     // the node's record in one round trip through the scalar cache: {type, data, flags, material} and rows 0..2 of its inverse
     pt_u32x4 info;
     pt_u32x16 a;  // doubles 0..7 of the 3x4 inverse
     pt_u32x8 b;   // doubles 8..11
-    const void* info_ptr = info_base + 4 * (size_t)node;
-    const void* rec = inv_base + 12 * (size_t)node;
+    const void* info_ptr = sc.info + 4 * (size_t)node;
+    const void* rec = sc.inv + 12 * (size_t)node;
 #if defined(__HIP_DEVICE_COMPILE__)
     pt_u32x8 hrec;  // HIER: the node's path record
     if (HIER) {  // ... the node's path record (hier_rec) and the inverse of its OWN level instead of a composed inverse
         asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\ts_load_dwordx16 %2, %6, 0x0\n\ts_load_dwordx8 %3, %6, 0x40\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(info), "=&s"(hrec), "=&s"(a), "=&s"(b)
-                     : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(sc.hier_rec + 8 * (size_t)node)), "s"(pt_uniform_ptr(rec)) : "memory");
+                     : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(sc.hier_rec + 8 * (size_t)node)), "s"(pt_uniform_ptr(sc.own_inv + 12 * (size_t)node)) : "memory");
     } else {
         asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(info), "=&s"(a), "=&s"(b) : "s"(pt_uniform_ptr(info_ptr)), "s"(pt_uniform_ptr(rec)) : "memory");
@@ -1543,17 +1536,6 @@ PT_HD void pt_descend_mesh(const PtBvhNode* bvh, const PtRayPk& q, float tm, uns
     }
 }
 
-// A wave-uniform pointer pinned to a scalar register pair (see pt_args_again: what is read through the re-read argument block would
-// otherwise be fetched again - one more dependent scalar load - in front of every use inside a loop).
-PT_HD const void* pt_pin_ptr(const void* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long a = (unsigned long long)pt_uniform_ptr(p);
-    asm volatile("" : "+s"(a));
-    return (const void*)a;
-#else
-    return p;
-#endif
-}
 // wstack: the wavefront's own stack in LDS, `wwords` 32-bit words, linear.
 template <bool STATS, bool HIER>
 PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray, bool any, PtHit& best, uint32_t* wstack, int wwords,
@@ -1575,13 +1557,6 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     uint32_t pops = 0;                   // (watchdog: pending subtrees taken by this walk, see pt_descend)
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(pops));       // (kept in a scalar register: left to itself the compiler parks it in a vector register's lane and spills four more of those)
-#endif
-#if defined(PT_PIN_LEAF_PTRS)  // (A/B: the arrays a leaf test reads its record from, held in scalar registers for the whole walk instead of re-read from the argument block per test)
-    const uint32_t* const info_base = static_cast<const uint32_t*>(pt_pin_ptr(sc.info));
-    const double* const inv_base = static_cast<const double*>(pt_pin_ptr(HIER ? sc.own_inv : sc.inv));
-#else
-    const uint32_t* const info_base = sc.info;
-    const double* const inv_base = HIER ? sc.own_inv : sc.inv;
 #endif
     for (;;) {
         bool overflowed = false;         // the stack overflowed or the watchdog tripped inside pt_descend
@@ -1617,7 +1592,7 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
             const uint32_t node = sc.tlas_direct ? first : PT_UNIFORM_U32(sc.bvh_items[first + i]);
             if (alive && (!STATS || (in & self))) {
                 if (STATS) cnt->n_leaf++;
-                if (pt_test_node_uniform_at<STATS, HIER>(sc, info_base, inv_base, node, ray, identity_ok, best, cnt)) {
+                if (pt_test_node_uniform<STATS, HIER>(sc, node, ray, identity_ok, best, cnt)) {
                     tm = pt_tmax32(best.t);
                     if (any) alive = false;
                 }
@@ -1646,6 +1621,17 @@ PT_HD void pt_trace_packet(const PtSceneView& sc, const PtRay& ray, bool has_ray
     }
 }
 
+// A wave-uniform pointer pinned to a scalar register pair (see pt_args_again: what is read through the re-read argument block would
+// otherwise be fetched again - one more dependent scalar load - in front of every use inside a loop).
+PT_HD const void* pt_pin_ptr(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long a = (unsigned long long)pt_uniform_ptr(p);
+    asm volatile("" : "+s"(a));
+    return (const void*)a;
+#else
+    return p;
+#endif
+}
 // The walk of ONE mesh instance's triangle tree (round 5), compiled once per octant of the participating lanes' rays: descents, triangle leaves and the
 // pops between them stay inside the specialised code until the instance's part of the stack is used up (`sp` back at its value on entry - no marker entry, no
 // marker test per pop, no re-dispatch on the octant per descent). Returns 0: instance finished, 1: stack overflow / watchdog, 2: no lane wants candidates any more.
