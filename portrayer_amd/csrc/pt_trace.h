@@ -2023,7 +2023,7 @@ PT_HD double pt_kd_sav_load(const PtKdSav& s, int level) {
 // like pt_trace_packet_mesh does, every triangle tested over [start, end of the lane's leaf fold) - nearest triangle, lowest index on
 // exact ties (pt_cand_end), which is what the reference's fold over ALL triangles with a shrinking range gives. `wstack`: free words
 // of the wavefront's stack. Returns false when they ran out.
-template <bool STATS, int OCT>
+template <bool STATS, int OCT, bool BIG>
 PT_HD bool pt_packet_mesh_below_kd_oct(const PtSceneView& sc, uint32_t inst, uint32_t root, const PtRay& local, const PtRayPk& q, bool part, double start, bool any, PtHit& lb, bool& found,
                                        uint32_t* wstack, int words, PtCounters* cnt) {
     float tm = pt_tmax32(lb.t);
@@ -2039,9 +2039,11 @@ PT_HD bool pt_packet_mesh_below_kd_oct(const PtSceneView& sc, uint32_t inst, uin
     uint32_t cur = root;
     int sp = 0;
     uint32_t steps = 0;  // (watchdog, as in pt_trace_packet_kd: leaves visited)
-    const PtBvhNode* const bvh = static_cast<const PtBvhNode*>(pt_pin_ptr(sc.bvh));  // (see pt_walk_instance)
+    // (see pt_walk_instance; only where the walk is long enough to earn the two fetches back - this function runs once per k-d leaf an instance spans, and pinned for the mirror
+    // scene's small meshes the k-d frame was 7 % slower: 41.1 -> 44.3 ms, c62)
+    const PtBvhNode* const bvh = BIG ? static_cast<const PtBvhNode*>(pt_pin_ptr(sc.bvh)) : sc.bvh;
 #if !defined(PT_TRI_VIA_ITEMS) && !defined(PT_NO_TRI_EDGES)
-    const double* const tri_leaf = static_cast<const double*>(pt_pin_ptr(sc.tri_leaf));
+    const double* const tri_leaf = BIG ? static_cast<const double*>(pt_pin_ptr(sc.tri_leaf)) : sc.tri_leaf;
 #endif
     for (;;) {
         if (!(cur & PT_REF_LEAF)) pt_descend_mesh<STATS, OCT, true>(bvh, q, tm, pmask, part, cur, sp, wstack, words, cnt, t0);
@@ -2088,19 +2090,28 @@ PT_HD bool pt_packet_mesh_below_kd(const PtSceneView& sc, uint32_t inst, uint32_
                                    uint32_t* wstack, int words, PtCounters* cnt) {
     // (only for trees deep enough to earn the octant's bookkeeping back: the 1.25 M-triangle soup +5.4 %; the mirror scene's and macho-cows' few-thousand-triangle
     // meshes, walked once per k-d leaf they span, lose 6.6 % / 3.7 % with it - c49)
+#ifndef PT_KD_BELOW_OCT
+    // ONE instantiation, the per-lane form. The octant instantiations (-DPT_KD_BELOW_OCT: taken by instances of >= 65,536 triangles) make the 1.25 M-triangle soup's k-d frame
+    // 8 - 10 % faster - and, by being in the kernel at all, the mirror scene's 6.4 % and macho-cows' 1.7 % slower (registers, code size): c64. The reference's own scenes decide.
+    (void)tri_count;
+    return pt_packet_mesh_below_kd_oct<STATS, PT_OCT_MIXED, false>(sc, inst, root, local, pt_raypk(local), part, start, any, lb, found, wstack, words, cnt);
+#else
     int oct = PT_OCT_MIXED;
     const PtRayPk q = (sc.mesh_oct && !STATS && tri_count >= 65536u) ? pt_raypk(local, part, &oct) : pt_raypk(local);
     switch (oct) {
-    case 0: return pt_packet_mesh_below_kd_oct<STATS, 0>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
-    case 1: return pt_packet_mesh_below_kd_oct<STATS, 1>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
-    case 2: return pt_packet_mesh_below_kd_oct<STATS, 2>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
-    case 3: return pt_packet_mesh_below_kd_oct<STATS, 3>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
-    case 4: return pt_packet_mesh_below_kd_oct<STATS, 4>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
-    case 5: return pt_packet_mesh_below_kd_oct<STATS, 5>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
-    case 6: return pt_packet_mesh_below_kd_oct<STATS, 6>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
-    case 7: return pt_packet_mesh_below_kd_oct<STATS, 7>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
-    default: return pt_packet_mesh_below_kd_oct<STATS, PT_OCT_MIXED>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 0: return pt_packet_mesh_below_kd_oct<STATS, 0, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 1: return pt_packet_mesh_below_kd_oct<STATS, 1, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 2: return pt_packet_mesh_below_kd_oct<STATS, 2, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 3: return pt_packet_mesh_below_kd_oct<STATS, 3, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 4: return pt_packet_mesh_below_kd_oct<STATS, 4, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 5: return pt_packet_mesh_below_kd_oct<STATS, 5, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 6: return pt_packet_mesh_below_kd_oct<STATS, 6, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    case 7: return pt_packet_mesh_below_kd_oct<STATS, 7, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+    default:
+        if (tri_count >= 65536u) return pt_packet_mesh_below_kd_oct<STATS, PT_OCT_MIXED, true>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
+        return pt_packet_mesh_below_kd_oct<STATS, PT_OCT_MIXED, false>(sc, inst, root, local, q, part, start, any, lb, found, wstack, words, cnt);
     }
+#endif
 }
 
 // One split of the k-d walk for the lanes in `mine` (node.rs:112-186): which side the ends of the lane's classification segment are on
@@ -2224,6 +2235,55 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                                  axis == 0 ? okx : (axis == 1 ? oky : okz), plane, t_min, t_max, start, end, mine, &s, &e, &cross, &strad, &plane_t);
 #endif
                 if (STATS && PT_LANES(cross & PT_MNOT(strad))) cnt->kd_plane_miss++;  // node.rs:146-147 / :177-178: the reference panics here; a miss for this subtree
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_KD_SPLIT_GENERAL_ONLY)  // (-DPT_KD_SPLIT_GENERAL_ONLY: every split through the general bookkeeping, the A/B of c62)
+                // The common case settled in seven scalar instructions (the pattern of pt_descend's step): no lane's segment crosses the plane and every lane is on one
+                // side - that child next, nothing waits, no range changes, code 0. `slow_`: everything else, through the general bookkeeping. ONE place assigns the node index.
+                uint32_t c_first, slow_, f_;
+                pt_mask t_;
+                asm volatile(
+                    "s_and_b64 %[t], %[mine], %[s]\n\t"
+                    "s_cselect_b32 %[next], %[cf], %[cb]\n\t"
+                    "s_cselect_b32 %[f], 1, 0\n\t"
+                    "s_andn2_b64 %[t], %[mine], %[s]\n\t"
+                    "s_cselect_b32 %[slow], %[f], 0\n\t"
+                    "s_cmp_lg_u64 %[cross], 0\n\t"
+                    "s_cselect_b32 %[slow], 1, %[slow]"
+                    : [next] "=&s"(c_first), [slow] "=&s"(slow_), [f] "=&s"(f_), [t] "=&s"(t_)
+                    : [mine] "s"(mine), [s] "s"(s), [cross] "s"(cross), [cf] "s"(v[3]), [cb] "s"(v[4])
+                    : "scc");
+                pt_mask in_first = mine;
+                uint32_t code = 0u;
+                descend = mine != 0ull && !failed;
+                if (slow_) {
+                    const pt_mask same = mine & PT_MNOT(s ^ e);
+                    const pt_mask go_f = (same & s) | strad, go_b = (same & PT_MNOT(s)) | strad;
+                    const bool front_first = PT_POPC((go_f | go_b) & s) >= PT_POPC((go_f | go_b) & PT_MNOT(s));
+                    c_first = front_first ? v[3] : v[4];
+                    const uint32_t c_second = front_first ? v[4] : v[3];
+                    in_first = front_first ? go_f : go_b;
+                    const pt_mask in_second = front_first ? go_b : go_f;
+                    const bool push = in_second != 0ull;
+                    const bool room = sp < wwords;
+                    if (room && push) wstack[sp] = (c_second << 5) | (uint32_t)lev;
+                    failed = failed || (push && !room);
+                    descend = (go_f | go_b) != 0ull && !failed;
+                    sp += (push && descend) ? 1 : 0;
+                    const pt_mask near_first = front_first ? s : PT_MNOT(s);
+                    const pt_mask both = (push && descend) ? strad : 0ull;
+                    if (lev < sav.top_levels) {
+                        if (push && descend) { sav.path[3 * lev] = v[0]; sav.path[3 * lev + 1] = v[1]; sav.path[3 * lev + 2] = v[2]; }
+                    } else if (both) pt_kd_sav_store(sav, lev, PT_LANES(near_first) ? end : start);
+                    if (push && descend) {
+                        code = PT_LANES(in_second) ? 1u : 0u;
+                        if (both) {
+                            code = PT_LANES(both & near_first) ? 2u : code;
+                            code = PT_LANES(both & PT_MNOT(near_first)) ? 3u : code;
+                            end = PT_LANES(both & near_first) ? plane_t : end;
+                            start = PT_LANES(both & PT_MNOT(near_first)) ? plane_t : start;
+                        }
+                    }
+                }
+#else
                 const pt_mask same = mine & PT_MNOT(s ^ e);
                 const pt_mask go_f = (same & s) | strad, go_b = (same & PT_MNOT(s)) | strad;
                 // the child most lanes call near goes first (a lane's near side is the side of its range start)
@@ -2256,6 +2316,7 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                         start = PT_LANES(both & PT_MNOT(near_first)) ? plane_t : start;
                     }
                 }
+#endif
                 if (descend) {
                     const int sh = 2 * (lev & 15);
                     if (lev < 16) codes_lo = (codes_lo & ~(3u << sh)) | (code << sh);
