@@ -1827,7 +1827,11 @@ PT_HD void pt_trace_packet_mesh(const PtSceneView& sc, const PtRay& ray, bool ha
 #ifndef PT_MESH_MARKER_WALK
                         {   // the instance's tree, in the code of its octant (pt_walk_instance); the scene-level walk goes on with this leaf's next node afterwards
                             int io = PT_OCT_MIXED;
+#ifdef PT_MESH_ONE_INSTANTIATION  // (A/B: what the eight octant copies of the instance walk cost the scenes with short walks by being in the kernel)
+                            const PtRayPk qi = pt_raypk(lr);
+#else
                             const PtRayPk qi = (sc.mesh_oct && !STATS) ? pt_raypk(lr, inside, &io) : pt_raypk(lr);
+#endif
                             int rc;
                             switch (io) {
                             case 0: rc = pt_walk_instance<STATS, HIER, 0>(sc, node, root, lr, qi, inside, any, alive, best, tm, wstack, sp, words, pops, cnt); break;
