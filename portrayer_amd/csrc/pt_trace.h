@@ -2198,6 +2198,13 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
     bool failed = false;   // wave-uniform: the wavefront's stack overflowed, or the watchdog below tripped
     uint32_t steps = 0;    // wave-uniform: nodes visited by this walk. A walk visits a node at most once; one that goes on beyond any tree this
                            // library accepts is a defect (or a corrupted stack) and fails the render (PT_ERR_TRAVERSAL) instead of hanging the GPU
+#ifndef PT_KD_SEG_PER_NODE
+    float seg0c = 0.0f, seg1c = 0.0f;
+    if (!MESH) {
+        seg0c = (float)start; seg1c = (float)end;
+        seg0c = seg0c - fabsf(seg0c) * 2.4e-7f; seg1c = seg1c + fabsf(seg1c) * 2.4e-7f;
+    }
+#endif
     for (;;) {
         steps++;
         failed = failed || steps > PT_KD_WALK_STEPS_MAX;
@@ -2210,8 +2217,16 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
             PT_WAVE_COUNT(4);
             // the lane's segment [start, end), rounded outward, against the conservative f32 bounds of everything below this node:
             // a subtree the segment does not reach reports no hit, which is all the reference would find out by walking it
+#ifndef PT_KD_SEG_PER_NODE  // (the f32 segment kept across nodes and converted again only where start / end change - a straddled split, a pop: +0.3 %, c70; -DPT_KD_SEG_PER_NODE: per node as before)
+            float seg0 = seg0c, seg1 = seg1c;
+            if (MESH) {  // (the instantiations with mesh walks below the leaves lose with the two registers held across the walk - mirror k-d -2.8 %, c71 - and convert per node)
+                seg0 = (float)start; seg1 = (float)end;
+                seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
+            }
+#else
             float seg0 = (float)start, seg1 = (float)end;
             seg0 = seg0 - fabsf(seg0) * 2.4e-7f; seg1 = seg1 + fabsf(seg1) * 2.4e-7f;
+#endif
             if (cull & 1u) {
                 const float lo[3] = {pt_f32_of(v[8]), pt_f32_of(v[9]), pt_f32_of(v[10])}, hi[3] = {pt_f32_of(v[11]), pt_f32_of(v[12]), pt_f32_of(v[13])};
                 const pt_mask reach = pt_slab_seg_pk_m(lo, hi, q, seg0, seg1);
@@ -2284,6 +2299,12 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                             code = PT_LANES(both & PT_MNOT(near_first)) ? 3u : code;
                             end = PT_LANES(both & near_first) ? plane_t : end;
                             start = PT_LANES(both & PT_MNOT(near_first)) ? plane_t : start;
+#ifndef PT_KD_SEG_PER_NODE
+                            if (!MESH) {
+                                seg0c = (float)start; seg1c = (float)end;
+                                seg0c = seg0c - fabsf(seg0c) * 2.4e-7f; seg1c = seg1c + fabsf(seg1c) * 2.4e-7f;
+                            }
+#endif
                         }
                     }
                 }
@@ -2476,6 +2497,12 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
             start = PT_LANES(need_s) ? (double)PT_EPSILON : start;
         }
         lev = L + 1;
+#ifndef PT_KD_SEG_PER_NODE
+        if (!MESH) {
+            seg0c = (float)start; seg1c = (float)end;
+            seg0c = seg0c - fabsf(seg0c) * 2.4e-7f; seg1c = seg1c + fabsf(seg1c) * 2.4e-7f;
+        }
+#endif
         if (done) break;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
