@@ -2274,6 +2274,41 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                 uint32_t code = 0u;
                 descend = mine != 0ull && !failed;
                 if (slow_) {
+#ifndef PT_KD_SLOW_COMPILER  // (the general case's mask algebra in one block of scalar instructions too - c61's block, which lost when every split issued it, issued only where all of it is needed: +0.9 %, c74; -DPT_KD_SLOW_COMPILER: the compiler's version)
+                    pt_mask go_f, go_b, in_second, t0_, t1_;
+                    uint32_t c_second, ff_, push_, any_, nf_, nb_;
+                    asm volatile(
+                        "s_xor_b64 %[t0], %[s], %[e]\n\t"
+                        "s_andn2_b64 %[t0], %[mine], %[t0]\n\t"
+                        "s_and_b64 %[gf], %[t0], %[s]\n\t"
+                        "s_or_b64 %[gf], %[gf], %[strad]\n\t"
+                        "s_andn2_b64 %[gb], %[t0], %[s]\n\t"
+                        "s_or_b64 %[gb], %[gb], %[strad]\n\t"
+                        "s_or_b64 %[t0], %[gf], %[gb]\n\t"
+                        "s_cselect_b32 %[any], 1, 0\n\t"
+                        "s_and_b64 %[t1], %[t0], %[s]\n\t"
+                        "s_bcnt1_i32_b64 %[nf], %[t1]\n\t"
+                        "s_andn2_b64 %[t1], %[t0], %[s]\n\t"
+                        "s_bcnt1_i32_b64 %[nb], %[t1]\n\t"
+                        "s_cmp_ge_u32 %[nf], %[nb]\n\t"
+                        "s_cselect_b32 %[ff], 1, 0\n\t"
+                        "s_cselect_b32 %[c1], %[cf], %[cb]\n\t"
+                        "s_cselect_b32 %[c2], %[cb], %[cf]\n\t"
+                        "s_cselect_b64 %[i1], %[gf], %[gb]\n\t"
+                        "s_cselect_b64 %[i2], %[gb], %[gf]\n\t"
+                        "s_cmp_lg_u64 %[i2], 0\n\t"
+                        "s_cselect_b32 %[push], 1, 0"
+                        : [gf] "=&s"(go_f), [gb] "=&s"(go_b), [i1] "=&s"(in_first), [i2] "=&s"(in_second), [t0] "=&s"(t0_), [t1] "=&s"(t1_), [c1] "=&s"(c_first), [c2] "=&s"(c_second),
+                          [ff] "=&s"(ff_), [push] "=&s"(push_), [any] "=&s"(any_), [nf] "=&s"(nf_), [nb] "=&s"(nb_)
+                        : [s] "s"(s), [e] "s"(e), [mine] "s"(mine), [strad] "s"(strad), [cf] "s"(v[3]), [cb] "s"(v[4])
+                        : "scc");
+                    const bool front_first = ff_ != 0u;
+                    const bool push = push_ != 0u;
+                    const bool room = sp < wwords;
+                    if (room && push) wstack[sp] = (c_second << 5) | (uint32_t)lev;
+                    failed = failed || (push && !room);
+                    descend = any_ != 0u && !failed;
+#else
                     const pt_mask same = mine & PT_MNOT(s ^ e);
                     const pt_mask go_f = (same & s) | strad, go_b = (same & PT_MNOT(s)) | strad;
                     const bool front_first = PT_POPC((go_f | go_b) & s) >= PT_POPC((go_f | go_b) & PT_MNOT(s));
@@ -2286,6 +2321,7 @@ PT_HD void pt_trace_packet_kd(const PtSceneView& sc, const PtRay& ray_in, bool h
                     if (room && push) wstack[sp] = (c_second << 5) | (uint32_t)lev;
                     failed = failed || (push && !room);
                     descend = (go_f | go_b) != 0ull && !failed;
+#endif
                     sp += (push && descend) ? 1 : 0;
                     const pt_mask near_first = front_first ? s : PT_MNOT(s);
                     const pt_mask both = (push && descend) ? strad : 0ull;
